@@ -1,0 +1,575 @@
+"""CPU oracle for the VBQ hot path  --  TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of
+``bench.py`` may import this module.  The product path (``vbq_amd``) never
+does; it fails loudly when the HIP extension is missing.
+
+What this is: a NumPy restatement of the algorithms of mandt-lab/vbq that sit on
+the hot path (file:line citations are into the reference tree):
+
+* dyadic xi grid ........................ img-compression/utils.py:23-24
+* code-point tables + search grids ...... img-compression/quantizer.py:25-63
+* per-level interval search ............. img-compression/quantizer.py:65-80
+* candidate / code-length assembly ...... img-compression/quantizer.py:156-188
+* distortion closure .................... img-compression/utils.py:307-327
+* per-lambda R-D solve .................. img-compression/utils.py:363-423
+* brute-force single vector solve ....... img-compression/utils.py:330-360
+* quantization index + entropy models ... img-compression/quantizer.py:82-150,223-228
+* compress_latents result dict .......... img-compression/quantizer.py:190-240
+* legacy xi-space encoder ............... img-compression/utils.py:27-78,215-304
+* notebook code book / brute force / entropy / moment
+                                          word-embeddings/compress-trained-word-embeddings.ipynb
+                                          (JSON lines 373-390, 429-455)
+* BMSHJ2018 prior cdf/pdf/inverse cdf ... img-compression/learned_prior.py:30-57,70-334
+* Gaussian priors ....................... img-compression/vae_models.py:14-43
+
+Pinning status (see tests/golden/README.md and DESIGN.md):
+
+* PINNED by golden vectors produced by running the reference's own NumPy code in
+  the build container (tests/golden/make_golden.py): the xi grid, the xi-space
+  interval functions, ``encode_vectorized``, ``batch_quantize_indep_dims`` (NumPy
+  backend, both the f32 op-by-op mode that reproduces the TF path's rounding and
+  the as-written f64 mode), ``quantize_indep_dims`` brute force, and the notebook
+  cells ``compress_coordinates`` / ``empirical_entropy`` / code book / moment.
+* RESTATED, cross-checked but not directly executable here (TensorFlow is not in
+  the image, quantizer.py / learned_prior.py import it at module top): the
+  interval search on padded grids, the candidate assembly and the two-pass entropy
+  model build.  Their semantics are pinned indirectly: the 21-candidate solve
+  built from them must equal the reference's exhaustive ``quantize_indep_dims``
+  over all 2047 code points (golden set G6).
+* PARITY UNPINNED: BMSHJ2018Prior numerics (TF kernels for matmul/softplus/tanh/
+  sigmoid; no checkpoint, stored table or test in the reference fixes its output).
+  Only self-consistency is tested.
+"""
+from __future__ import annotations
+
+import collections
+from typing import Callable, Dict, Iterable, Sequence, Tuple
+
+import numpy as np
+
+F32 = np.float32
+
+
+# --------------------------------------------------------------------------------------
+# dyadic grid, tables, search grids
+# --------------------------------------------------------------------------------------
+def n_bit_binary_floats(n: int) -> np.ndarray:
+    """xi representatives with exactly n binary digits plus an implied trailing 1:
+    (i + 1/2) / 2**n, i < 2**n.  (utils.py:23-24; values are exact dyadic f64.)"""
+    return (np.arange(2 ** n, dtype=np.float64) + 0.5) / float(2 ** n)
+
+
+def dyadic_xi(N: int) -> np.ndarray:
+    """All levels 0..N stacked level-major: 2**(N+1)-1 values (quantizer.py:30)."""
+    return np.concatenate([n_bit_binary_floats(n) for n in range(N + 1)])
+
+
+def level_slices(N: int):
+    """[start, stop) of level n inside a level-major table (quantizer.py:44)."""
+    return [(2 ** n - 1, 2 ** (n + 1) - 1) for n in range(N + 1)]
+
+
+def build_code_points(inverse_cdf: Callable[[np.ndarray], np.ndarray], C: int, N: int):
+    """quantizer.py:25-63.  Returns (all_code_points[C,T] level-major f32,
+    code_points_by_channel[C,T] sorted f32, search_grids[C,N+1,2**N] f32)."""
+    xi = dyadic_xi(N)
+    xi_rep = np.repeat(xi[:, None], C, axis=1)                    # T x C  (:31-32)
+    pts = np.asarray(inverse_cdf(xi_rep))                         # T x C  (:33)
+    all_pts = np.ascontiguousarray(pts.astype(F32).T)             # C x T  (:34-35)
+    by_channel = np.sort(all_pts, axis=1)                         # (:37)
+    grids = np.empty((C, N + 1, 2 ** N), dtype=F32)
+    for c in range(C):
+        for n, (a, b) in enumerate(level_slices(N)):
+            lvl = all_pts[c, a:b]
+            if n == 0:                                            # (:54-55)
+                grids[c, n] = np.pad(np.array([lvl[0], lvl[0]]), (2 ** (N - 1) - 1,), "edge")
+            else:                                                 # (:56-57)
+                grids[c, n] = np.pad(lvl, (2 ** (N - 1) - 2 ** (n - 1),), "edge")
+    return all_pts, by_channel, grids
+
+
+def get_all_N_bit_intervals(search_grids: np.ndarray, Z: np.ndarray):
+    """quantizer.py:65-80.  Z is B x C; returns (left, right), each C x (N+1) x B."""
+    C, N1, G = search_grids.shape
+    B = Z.shape[0]
+    left = np.empty((C, N1, B), dtype=search_grids.dtype)
+    right = np.empty_like(left)
+    for c in range(C):
+        zc = Z[:, c]
+        for n in range(N1):
+            g = search_grids[c, n]
+            r = np.clip(np.searchsorted(g, zc, side="left"), 0, G - 1)    # (:74-75)
+            l = np.clip(r - 1, 0, G - 1)                                   # (:76)
+            right[c, n] = g[r]
+            left[c, n] = g[l]
+    return left, right
+
+
+def assemble_candidates(left: np.ndarray, right: np.ndarray) -> np.ndarray:
+    """quantizer.py:163-164,183: (2N+1) x B x C in the order [L_0..L_N, R_1..R_N]."""
+    Lt = np.transpose(left, (1, 2, 0))
+    Rt = np.transpose(right, (1, 2, 0))
+    return np.concatenate([Lt, Rt[1:]], axis=0)
+
+
+def raw_code_lengths(N: int, B: int, C: int) -> np.ndarray:
+    """quantizer.py:167-169: int32 (2N+1) x B x C."""
+    lv = np.arange(N + 1, dtype=np.int32)
+    lv = np.concatenate([lv, lv[1:]])
+    return np.broadcast_to(lv[:, None, None], (2 * N + 1, B, C)).copy()
+
+
+def corrected_level_lengths(N: int, raw_model: np.ndarray) -> np.ndarray:
+    """quantizer.py:171-175 for one lambda: f32 (N+1) x C, n + overhead_c(n)."""
+    lv = np.arange(N + 1, dtype=np.int32)[:, None].astype(raw_model.dtype)
+    return lv + raw_model.T
+
+
+def corrected_code_lengths(N: int, B: int, raw_models: Sequence[np.ndarray]) -> np.ndarray:
+    """quantizer.py:171-180: f32 L x (2N+1) x B x C."""
+    out = []
+    for m in raw_models:
+        per_level = corrected_level_lengths(N, m)                 # (N+1) x C
+        rep = np.repeat(per_level[:, None, :], B, axis=1)
+        out.append(np.concatenate([rep, rep[1:]], axis=0))
+    return np.stack(out)
+
+
+# --------------------------------------------------------------------------------------
+# the R-D inner loop
+# --------------------------------------------------------------------------------------
+def neg_half_sq_err(mu: np.ndarray, sigma: np.ndarray):
+    """utils.py:319-320 (ignore_const=True): four separately rounded ops."""
+    def f(z):
+        return -0.5 * ((z - mu) / sigma) ** 2
+    return f
+
+
+def rd_solve(P: np.ndarray, Lens: np.ndarray, mu: np.ndarray, sigma: np.ndarray,
+             lambs: Sequence, mode: str = "f32"):
+    """utils.py:363-423 with 3-D / 4-D inputs.
+
+    mode "f32": lengths cast to P.dtype and lambda to np.float32 -- every op rounds
+        to f32 exactly as the TF-eager path does (utils.py:388,394-396).
+    mode "f64": the NumPy backend as written under NumPy-1.17 casting: f32
+        distortion, lambda*L evaluated in f64 (integer lengths), f64 scores.
+    Returns (Z_hat[L,B,C], num_bits[L,B,C], winner[L,B,C] int64).
+    """
+    M = P.shape[0]
+    fun_P = neg_half_sq_err(mu, sigma)(P)                         # (:387)
+    per_lambda = Lens.ndim == 4
+    Zs, Bs, Is = [], [], []
+    for i, lamb in enumerate(lambs):
+        Li = Lens[i] if per_lambda else Lens
+        if mode == "f32":
+            pen = F32(lamb) * Li.astype(P.dtype)
+            scores = fun_P - pen
+        elif mode == "f64":
+            pen = np.float64(lamb) * Li.astype(np.float64)
+            scores = fun_P.astype(np.float64) - pen
+        else:
+            raise ValueError(mode)
+        best = scores[0].copy()
+        win = np.zeros(best.shape, dtype=np.int64)
+        for j in range(1, M):                                     # first maximum wins (:401)
+            upd = scores[j] > best
+            best = np.where(upd, scores[j], best)
+            win = np.where(upd, j, win)
+        Zs.append(np.take_along_axis(P, win[None], axis=0)[0])
+        Bs.append(np.take_along_axis(np.broadcast_to(Li, P.shape), win[None], axis=0)[0])
+        Is.append(win)
+    return np.stack(Zs), np.stack(Bs), np.stack(Is)
+
+
+def brute_force_solve(z_row, sigma_row, tables_sorted, lengths_sorted, lamb, mode="f32"):
+    """utils.py:330-360 for one row: every one of the T sorted code points of each
+    channel is scored; first maximum in sorted order wins."""
+    P = tables_sorted.T                                           # T x C
+    Lt = lengths_sorted.T
+    d = neg_half_sq_err(z_row, sigma_row)(P)
+    if mode == "f32":
+        scores = d - F32(lamb) * Lt.astype(P.dtype)
+    else:
+        scores = d.astype(np.float64) - np.float64(lamb) * Lt.astype(np.float64)
+    idx = np.argmax(scores, axis=0)
+    cols = np.arange(P.shape[1])
+    return P[idx, cols], Lt[idx, cols], idx
+
+
+def levels_of_sorted_ranks(N: int) -> np.ndarray:
+    """Raw bit length of each entry of a sorted (strictly increasing) table:
+    rank k = 1..T has xi = k / 2**(N+1) and level N - ctz(k)."""
+    k = np.arange(1, 2 ** (N + 1))
+    ctz = np.zeros_like(k)
+    kk = k.copy()
+    for _ in range(N + 1):
+        even = (kk & 1) == 0
+        ctz += even
+        kk = np.where(even, kk >> 1, kk)
+    return (N - ctz).astype(np.int32)
+
+
+def level_major_to_rank(N: int) -> np.ndarray:
+    """rank-1 (0-based sorted position) of every level-major slot: slot (n, i) has
+    xi = (2i+1)/2**(n+1) = k / 2**(N+1) with k = (2i+1) * 2**(N-n)."""
+    out = []
+    for n in range(N + 1):
+        i = np.arange(2 ** n)
+        out.append((2 * i + 1) * 2 ** (N - n) - 1)
+    return np.concatenate(out)
+
+
+def qidx_lookup(by_channel: np.ndarray, Z_hat: np.ndarray) -> np.ndarray:
+    """quantizer.py:135,223: lower bound of each value in its channel's sorted table.
+    Z_hat is B x C, result C x B."""
+    C = by_channel.shape[0]
+    return np.stack([np.searchsorted(by_channel[c], Z_hat[:, c], side="left") for c in range(C)])
+
+
+def neg_log2_freq(counts: np.ndarray, add_n_smoothing, float_type=F32) -> np.ndarray:
+    """quantizer.py:104-109 / 138-144: counts (C x K, any int) -> -log2 of smoothed
+    frequencies, computed in `float_type` exactly as the reference does."""
+    c = np.array(counts, dtype=float_type)
+    c += add_n_smoothing
+    freqs = c / np.sum(c, axis=1)[:, None]
+    return -np.log2(freqs)
+
+
+class ChannelwiseOracle:
+    """State + methods of ChannelwisePriorCDFQuantizer (quantizer.py:13-256), minus
+    the VAE: works on (means, stds) matrices directly."""
+
+    def __init__(self, num_channels: int, max_bits_per_coord: int):
+        self.C = num_channels
+        self.N = max_bits_per_coord
+        self.T = 2 ** (max_bits_per_coord + 1) - 1                # (:20)
+        self.raw_models: Dict = {}
+        self.entropy_models: Dict = {}
+
+    def build_code_points(self, inverse_cdf):
+        self.all_code_points, self.by_channel, self.grids = build_code_points(inverse_cdf, self.C, self.N)
+
+    def compress_batch(self, means, stds, lambs, mode="f32"):
+        """quantizer.py:156-188 -> (Z_hat[L,B,C], num_bits[L,B,C])."""
+        B, C = means.shape
+        left, right = get_all_N_bit_intervals(self.grids, means)
+        P = assemble_candidates(left, right)
+        if not self.raw_models:                                   # (:166)
+            Lens = raw_code_lengths(self.N, B, C)
+        else:
+            Lens = corrected_code_lengths(self.N, B, [self.raw_models[l] for l in lambs])
+        Z, bits, _ = rd_solve(P, Lens, means, stds, lambs, mode=mode)
+        return Z, bits
+
+    def build_entropy_models(self, means, stds, lambs, add_n_smoothing=1, mode="f32"):
+        """quantizer.py:82-150 (vae.encode replaced by its outputs)."""
+        N, C = self.N, self.C
+        self.raw_models = {}
+        Z1, bits1 = self.compress_batch(means, stds, lambs, mode=mode)
+        raw_models = {}
+        for i, lamb in enumerate(lambs):
+            counts = np.array([np.bincount(bits1[i][:, c].astype(np.int64), minlength=N + 1)
+                               for c in range(C)])
+            raw_models[lamb] = neg_log2_freq(counts, add_n_smoothing)
+        self.raw_models = raw_models
+        Z2, bits2 = self.compress_batch(means, stds, lambs, mode=mode)
+        models = {}
+        for i, lamb in enumerate(lambs):
+            q = qidx_lookup(self.by_channel, Z2[i])
+            assert np.array_equal(np.take_along_axis(self.by_channel, q, axis=1), Z2[i].T)   # (:136-137)
+            counts = np.array([np.bincount(q[c], minlength=self.T) for c in range(C)])
+            models[lamb] = neg_log2_freq(counts, add_n_smoothing)
+        self.entropy_models = models
+        return (Z1, bits1), (Z2, bits2)
+
+    def compress_latents(self, means, stds, lambs, mode="f32"):
+        """quantizer.py:190-240 on (B x C) inputs; returns the same dict of dicts."""
+        Z, bits = self.compress_batch(means, stds, lambs, mode=mode)
+        out = {k: {} for k in ("Z_hat", "raw_num_bits", "num_bits_cl", "num_bits")}
+        for i, lamb in enumerate(lambs):
+            q = qidx_lookup(self.by_channel, Z[i])
+            nb = np.take_along_axis(self.entropy_models[lamb], q, axis=1).T
+            out["Z_hat"][lamb] = Z[i]
+            out["raw_num_bits"][lamb] = bits[i]
+            if self.raw_models:
+                out["num_bits_cl"][lamb] = bits[i]
+            out["num_bits"][lamb] = nb
+        return out
+
+
+# --------------------------------------------------------------------------------------
+# merged-table ("rank") formulation of the interval search.  This is the form the C
+# oracle's fast path and the HIP kernel use; here it exists to be tested against the
+# grid formulation above.
+# --------------------------------------------------------------------------------------
+def interval_ranks(table_sorted: np.ndarray, z: np.ndarray, N: int):
+    """For a non-decreasing table of T = 2**(N+1)-1 points (rank k = index+1) return
+    (k_left[N+1,B], k_right[N+1,B]) such that table[k-1] reproduces
+    get_all_N_bit_intervals() for every level."""
+    T = table_sorted.shape[0]
+    klb = np.searchsorted(table_sorted, z, side="left") + 1       # first rank with value >= z; T+1 if none
+    kl = np.empty((N + 1, z.shape[0]), dtype=np.int64)
+    kr = np.empty_like(kl)
+    for n in range(N + 1):
+        s = 2 ** (N - n)
+        kmin, kmax = s, 2 ** (N + 1) - s
+        r = ((klb - s + 2 * s - 1) // (2 * s)) * (2 * s) + s      # smallest odd multiple of s that is >= klb
+        r = np.maximum(r, kmin)
+        over = r > kmax
+        r = np.minimum(r, kmax)
+        l = np.maximum(r - 2 * s, kmin)
+        if n < N:
+            l = np.where(over, kmax, l)                           # edge padding: both endpoints collapse
+        if n == 0:
+            l = r
+        kl[n], kr[n] = l, r
+    return kl, kr
+
+
+# --------------------------------------------------------------------------------------
+# legacy xi-space encoder (utils.py:27-78, 215-304)
+# --------------------------------------------------------------------------------------
+def get_n_bit_interval(x: float, n: int):
+    """utils.py:27-57, closed form."""
+    if n == 0:
+        return (0.5, 0.5)
+    w = 2.0 ** (-n)
+    off = w / 2
+    if x < off:
+        return (off, off)
+    if x > 1 - off:
+        return (1 - off, 1 - off)
+    left = np.floor((x - off) / w) * w + off
+    return (float(left), float(left + w))
+
+
+def xi_intervals(x: np.ndarray, N: int):
+    """utils.py:215-260 (the numba kernel), vectorised closed form."""
+    K = x.shape[0]
+    left = np.empty((N + 1, K))
+    right = np.empty((N + 1, K))
+    left[0] = right[0] = 0.5
+    for n in range(1, N + 1):
+        w = 2.0 ** (-n)
+        off = w * 0.5
+        lo, hi = off, 1.0 - off
+        l = np.floor((x - off) / w) * w + off
+        r = l + w
+        below = x < lo
+        above = x > hi
+        l = np.where(below, lo, np.where(above, hi, l))
+        r = np.where(below, lo, np.where(above, hi, r))
+        left[n], right[n] = l, r
+    return left, right
+
+
+def encode_vectorized(fun, z, lamb, squash, unsquash, N):
+    """utils.py:263-304."""
+    K = len(z)
+    L, R = xi_intervals(squash(z), N)
+    ends = np.stack([L, R])
+    zs = unsquash(ends)
+    F = fun(zs)
+    pick = np.argmax(F, axis=0)
+    Fm = np.take_along_axis(F, pick[None], axis=0)[0]
+    zb = np.take_along_axis(zs, pick[None], axis=0)[0]
+    xb = np.take_along_axis(ends, pick[None], axis=0)[0]
+    reg = Fm - lamb * np.arange(N + 1)[:, None]
+    nb = np.argmax(reg, axis=0)
+    cols = np.arange(K)
+    return dict(z_hat=zb[nb, cols], score=np.sum(reg[nb, cols]), num_bits=nb, xi_hat=xb[nb, cols])
+
+
+# --------------------------------------------------------------------------------------
+# notebook path (word embeddings)
+# --------------------------------------------------------------------------------------
+def empirical_std(means: np.ndarray):
+    """ipynb:374: sqrt(mean(mu**2)) in the array's own precision."""
+    return np.sqrt(np.mean(means.ravel() ** 2))
+
+
+def notebook_code_book(std, max_len: int):
+    """ipynb:383-390: level-major f64 code points norm.ppf(xi, scale=std) and int lengths."""
+    from scipy.stats import norm
+    pts, lens = [], []
+    for length in range(max_len + 1):
+        for xi in np.arange(0.5 ** (length + 1), 1, 0.5 ** length):
+            pts.append(norm.ppf(xi, scale=std))
+            lens.append(length)
+    return np.array(pts), np.array(lens)
+
+
+def compress_coordinates(means, stds, beta, codepoints, bitlengths, chunk=100000):
+    """ipynb:429-443 (returns the array, not the (array, None) tuple).  `beta` must be
+    a Python float so that (2*beta)*stds**2 stays f32 as under NumPy 1.17."""
+    beta = float(beta)
+    out = np.empty_like(means)
+    flat_m, flat_s, flat_o = means.ravel(), stds.ravel(), out.ravel()
+    for i in range(0, flat_m.shape[0], chunk):
+        m = flat_m[i:i + chunk, None]
+        s = flat_s[i:i + chunk, None]
+        err = (codepoints[None, :] - m) ** 2
+        pen = (2 * beta) * s ** 2 * bitlengths[None, :]
+        idx = np.argmin(err + pen, axis=1)
+        flat_o[i:i + chunk] = codepoints[idx]
+    return out
+
+
+def compress_coordinates_idx(means, stds, beta, codepoints, bitlengths, chunk=100000):
+    """Same solve, returning the winning level-major slot (for index parity checks)."""
+    beta = float(beta)
+    flat_m, flat_s = means.ravel(), stds.ravel()
+    idx = np.empty(flat_m.shape[0], dtype=np.int64)
+    for i in range(0, flat_m.shape[0], chunk):
+        m = flat_m[i:i + chunk, None]
+        s = flat_s[i:i + chunk, None]
+        idx[i:i + chunk] = np.argmin((codepoints[None, :] - m) ** 2
+                                     + (2 * beta) * s ** 2 * bitlengths[None, :], axis=1)
+    return idx.reshape(means.shape)
+
+
+def empirical_entropy(values: np.ndarray) -> float:
+    """ipynb:452-455: N log2 N - sum c log2 c over the multiset of values."""
+    counts = np.array(list(collections.Counter(values.ravel().tolist()).values()))
+    tot = counts.sum()
+    return tot * np.log2(tot) - counts.dot(np.log2(counts))
+
+
+def entropy_from_counts(counts: np.ndarray) -> float:
+    c = np.asarray(counts, dtype=np.float64)
+    c = c[c > 0]
+    tot = c.sum()
+    return float(tot * np.log2(tot) - c.dot(np.log2(c)))
+
+
+# --------------------------------------------------------------------------------------
+# priors
+# --------------------------------------------------------------------------------------
+def standard_gaussian_icdf(xi):
+    """vae_models.py:24-25."""
+    from scipy.stats import norm
+    return norm.ppf(xi)
+
+
+def factored_gaussian_icdf(mean, std):
+    """vae_models.py:40-43."""
+    from scipy.stats import norm
+    mean = np.asarray(mean)
+    std = np.asarray(std)
+
+    def icdf(xi):
+        assert xi.shape[-1] == len(mean)
+        return norm.ppf(xi, loc=mean, scale=std)
+    return icdf
+
+
+class BMSHJ2018Oracle:
+    """learned_prior.py:6-334 evaluated in f32 NumPy on *effective* parameters
+    (softplus(matrix), bias, tanh(factor)); see SURVEY 7.2 item 7."""
+
+    def __init__(self, matrices, biases, factors):
+        self.matrices = [np.asarray(m, dtype=F32) for m in matrices]   # [C, d_{i+1}, d_i], already softplus'ed
+        self.biases = [np.asarray(b, dtype=F32) for b in biases]       # [C, d_{i+1}, 1]
+        self.factors = [np.asarray(f, dtype=F32) for f in factors]     # [C, d_{i+1}, 1], already tanh'ed
+        self.C = self.matrices[0].shape[0]
+
+    @staticmethod
+    def init_params(channels, dims=(3, 3, 3), init_scale=10.0, rng=None):
+        """learned_prior.py:30-57: raw (pre-softplus / pre-tanh) initial values."""
+        rng = rng or np.random.default_rng(0)
+        d = (1,) + tuple(dims) + (1,)
+        scale = float(init_scale) ** (1 / (len(dims) + 1))
+        mats, bias, fac = [], [], []
+        for i in range(len(dims) + 1):
+            init = np.log(np.expm1(1 / scale / d[i + 1]))
+            mats.append(np.full((channels, d[i + 1], d[i]), init, dtype=F32))
+            bias.append(rng.uniform(-0.5, 0.5, size=(channels, d[i + 1], 1)).astype(F32))
+            if i < len(dims):
+                fac.append(np.zeros((channels, d[i + 1], 1), dtype=F32))
+        return mats, bias, fac
+
+    @staticmethod
+    def effective(mats, bias, fac):
+        sp = [np.logaddexp(F32(0), m).astype(F32) for m in mats]
+        return sp, bias, [np.tanh(f).astype(F32) for f in fac]
+
+    def _to_cb(self, x):
+        x = np.asarray(x, dtype=F32)
+        assert x.shape[-1] == self.C
+        return np.moveaxis(x, -1, 0).reshape(self.C, 1, -1), x.shape
+
+    def _from_cb(self, y, shape):
+        return np.moveaxis(y.reshape((self.C,) + shape[:-1]), 0, -1)
+
+    def logits(self, h):
+        for i, (M, b) in enumerate(zip(self.matrices, self.biases)):
+            h = np.matmul(M, h) + b                                   # (:94,99)
+            if i < len(self.factors):
+                h = h + self.factors[i] * np.tanh(h)                  # (:105)
+        return h
+
+    def cdf(self, x):
+        h, shape = self._to_cb(x)
+        lg = self.logits(h)
+        return self._from_cb((1 / (1 + np.exp(-lg))).astype(F32), shape)   # (:140)
+
+    def cdf_pdf(self, x):
+        """learned_prior.py:244-334: analytic Jacobian chain."""
+        h, shape = self._to_cb(x)
+        jac = None
+        for i, (M, b) in enumerate(zip(self.matrices, self.biases)):
+            h = np.matmul(M, h) + b
+            if i < len(self.factors):
+                t = np.tanh(h)
+                h = h + self.factors[i] * t
+                g = 1 + self.factors[i] * (1 - t ** 2)                # (:301-302)
+            else:
+                cdf = (1 / (1 + np.exp(-h))).astype(F32)
+                g = cdf * (1 - cdf)                                   # (:305)
+            J = np.transpose(g, (2, 0, 1))[..., None] * M              # [B, C, r, d]  (:312-314)
+            jac = J if jac is None else np.matmul(J, jac)
+        pdf = np.transpose(jac[..., 0], (1, 2, 0))                     # [C, 1, B]
+        return self._from_cb(cdf, shape), self._from_cb(pdf.astype(F32), shape)
+
+    def pdf(self, x):
+        return self.cdf_pdf(x)[1]
+
+    def logpdf(self, x):
+        return np.log(self.pdf(x) + F32(1e-10))                        # (:242)
+
+    def inverse_cdf(self, xi, max_iterations=1000, tol=1e-9):
+        """learned_prior.py:173-218, bisection with the reference's global stopping rule."""
+        xi = np.asarray(xi)
+        left = np.full(xi.shape, -1, dtype=F32)
+        right = np.full(xi.shape, 1, dtype=F32)
+
+        def f(z):
+            return self.cdf(z) - xi
+        while not np.all(f(left) < 0):
+            left = left * 2
+        while not np.all(f(right) > 0):
+            right = right * 2
+        its = 0
+        for i in range(max_iterations):
+            mid = F32(0.5) * (left + right)
+            v = f(mid)
+            pos, neg = v > 0, v < 0
+            left = left * (~neg).astype(F32) + mid * neg.astype(F32)
+            right = right * (~pos).astype(F32) + mid * pos.astype(F32)
+            its = i
+            if np.all(~pos & ~neg) or np.min(right - left) <= tol:
+                break
+        self.last_iterations = its
+        return mid
+
+
+# --------------------------------------------------------------------------------------
+# R-D bookkeeping used by the parity gates
+# --------------------------------------------------------------------------------------
+def lagrangian(mu, sigma, z_hat, bits, lamb) -> float:
+    """sum[(z_hat-mu)^2/(2 sigma^2) + lambda*R] in f64 (SURVEY 8d parity gate)."""
+    mu = mu.astype(np.float64)
+    sigma = sigma.astype(np.float64)
+    d = ((z_hat.astype(np.float64) - mu) / sigma) ** 2 * 0.5
+    return float(d.sum() + float(lamb) * bits.astype(np.float64).sum())

@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by RUNNING THE REFERENCE's own
+NumPy code (read-only, from /root/reference) in the build container.
+
+    python tests/golden/make_golden.py            # rewrites tests/golden/*.npz
+
+Only data (inputs + the reference's outputs) is written; no reference source travels.
+The reference tree does not exist on the GPU box, so this script is never run there.
+
+What is executed from the reference:
+  * img-compression/utils.py, imported as a module.  It does `from numba import jit`
+    at :211; numba is not installed here, so an identity decorator is registered
+    under that name first (`@jit(nopython=True)` does not change semantics).
+  * the notebook cells that define the word-embedding VBQ (cells 25, 26, 28, 29 of
+    word-embeddings/compress-trained-word-embeddings.ipynb), exec'd from the JSON.
+What cannot be executed (TensorFlow is absent): quantizer.py and learned_prior.py.
+The candidate tensors fed to the reference's batch_quantize_indep_dims are therefore
+built by oracle/vbq_oracle.py (our restatement of quantizer.py:25-80,156-183); G6
+ties that construction back to the reference through its exhaustive
+quantize_indep_dims over the full code book.
+
+NumPy-version note: the reference ran under NumPy 1.17 where a
+np.float64 scalar times an f32 array stays f32.  Under NumPy 2 that needs a Python
+float / np.float32 scalar, which is what is passed below.
+"""
+import json
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+import numpy as np
+from scipy.stats import norm
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("VBQ_REFERENCE", "/root/reference")
+sys.path.insert(0, ROOT)
+
+_nb = types.ModuleType("numba")
+_nb.jit = lambda *a, **k: (lambda f: f)
+sys.modules.setdefault("numba", _nb)
+sys.path.insert(0, os.path.join(REF, "img-compression"))
+import utils as ref_utils  # noqa: E402  (the reference module)
+
+from oracle import vbq_oracle as O  # noqa: E402
+
+N = 10
+LAMBDAS32 = (2.0 ** np.linspace(-8, 7.5, 32))
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrays)
+    print("wrote", name, {k: getattr(v, "shape", None) for k, v in arrays.items()})
+
+
+# ---------------------------------------------------------------- G1 / G2 / G3
+def g1_g2_g3():
+    xi = np.concatenate([np.array(ref_utils.n_bit_binary_floats(n), dtype=np.float64) for n in range(N + 1)])
+    save("g1_xi_grid.npz", xi=xi, N=np.int64(N))
+
+    rng = np.random.default_rng(101)
+    xs = np.concatenate([[0.4375, 0.004375, 0.04375, 0.0, 1.0, 0.5, 0.25, 0.75, 0.999, 1e-9],
+                         rng.uniform(0, 1, 40)])
+    ns = np.concatenate([[2, 2, 5, 3, 3, 1, 2, 2, 10, 10], rng.integers(0, 11, 40)]).astype(np.int64)
+    lr = np.array([ref_utils.get_n_bit_interval(float(x), int(n)) for x, n in zip(xs, ns)], dtype=np.float64)
+    save("g2_n_bit_interval.npz", x=xs, n=ns, left=lr[:, 0], right=lr[:, 1])
+
+    x = np.concatenate([rng.uniform(0, 1, 300), [0.0, 1.0, 0.5, 2.0 ** -11, 1 - 2.0 ** -11, 0.25, 0.375]])
+    L = np.empty((N + 1, x.shape[0]))
+    R = np.empty_like(L)
+    ref_utils.get_all_N_bit_intervals(x, N, L, R)
+    save("g3_xi_intervals.npz", x=x, left=L, right=R, N=np.int64(N))
+
+
+# ---------------------------------------------------------------- G4
+def g4():
+    rng = np.random.default_rng(104)
+    K = 200
+    mu = rng.normal(0, 1.0, K)
+    sigma = np.exp(rng.normal(-2, 0.7, K))
+    fun = ref_utils.curry_normal_logpdf(loc=mu, scale=sigma, ignore_const=False, backend=np)
+    lambs = np.array([2.0 ** -8, 0.1, 1.0, 7.3, 128.0])
+    zh, nb, xh, sc = [], [], [], []
+    for lamb in lambs:
+        r = ref_utils.encode_vectorized(fun, mu, float(lamb), norm.cdf, norm.ppf, max_bits_per_coord=N)
+        zh.append(r["z_hat"]); nb.append(r["num_bits"]); xh.append(r["xi_hat"]); sc.append(r["score"])
+    save("g4_encode_vectorized.npz", mu=mu, sigma=sigma, lambs=lambs, z_hat=np.array(zh),
+         num_bits=np.array(nb), xi_hat=np.array(xh), score=np.array(sc), N=np.int64(N))
+
+
+# ---------------------------------------------------------------- G5 / G6 / G8
+def make_image_case(seed, B, C):
+    rng = np.random.default_rng(seed)
+    ch_mean = rng.normal(0, 0.3, C)
+    ch_std = np.exp(rng.uniform(np.log(0.3), np.log(3.0), C))
+    orc = O.ChannelwiseOracle(C, N)
+    orc.build_code_points(O.factored_gaussian_icdf(ch_mean, ch_std))
+    mu = (ch_mean + ch_std * rng.normal(0, 1, (B, C))).astype(np.float32)
+    sigma = np.clip(np.exp(rng.normal(-2, 0.7, (B, C))), 1e-4, 10).astype(np.float32)
+    # edge rows: exact code-point hits, far outside the table, tiny / huge sigma, table min / max
+    for c in range(C):
+        t = orc.by_channel[c]
+        mu[0, c] = t[rng.integers(0, t.shape[0])]
+        mu[1, c] = np.float32(50.0)
+        mu[2, c] = np.float32(-50.0)
+        mu[3, c] = t[0]
+        mu[4, c] = t[-1]
+        mu[5, c] = t[1023]                       # the 0-bit point
+        mu[6, c] = np.nextafter(t[1023], np.float32(np.inf))
+        mu[7, c] = 0.5 * (t[1000] + t[1001])
+    sigma[8] = np.float32(1e-4)
+    sigma[9] = np.float32(10.0)
+    return orc, mu, sigma, ch_mean, ch_std
+
+
+def g5_g6_g8():
+    B, C = 192, 4
+    orc, mu, sigma, ch_mean, ch_std = make_image_case(105, B, C)
+    left, right = O.get_all_N_bit_intervals(orc.grids, mu)
+    P = O.assemble_candidates(left, right)
+    Lraw = O.raw_code_lengths(N, B, C)
+    fun = ref_utils.curry_normal_logpdf(loc=mu, scale=sigma, ignore_const=True, backend=object())  # the TF-branch closure
+    # f32 op-by-op mode (what the TF path computes): lengths cast to f32, lambda as np.float32
+    lam32 = [np.float32(l) for l in LAMBDAS32]
+    Zd, Bd = ref_utils.batch_quantize_indep_dims((B, C), P, Lraw.astype(np.float32), fun, lambs=lam32,
+                                                 backend=np, return_np=True)
+    Z32 = np.stack([Zd[l] for l in lam32]); B32 = np.stack([Bd[l] for l in lam32])
+    # as-written NumPy mode: int lengths, Python-float lambda -> f64 scores
+    lam64 = [float(l) for l in LAMBDAS32]
+    Zd, Bd = ref_utils.batch_quantize_indep_dims((B, C), P, Lraw, fun, lambs=lam64, backend=np, return_np=True)
+    Z64 = np.stack([Zd[l] for l in lam64]); B64 = np.stack([Bd[l] for l in lam64])
+    save("g5_batch_quantize.npz", mu=mu, sigma=sigma, ch_mean=ch_mean, ch_std=ch_std,
+         all_code_points=orc.all_code_points, lambdas=LAMBDAS32, N=np.int64(N),
+         zhat_f32=Z32, bits_f32=B32.astype(np.int32), zhat_f64=Z64, bits_f64=B64.astype(np.int32))
+
+    # G8: corrected-length second pass.  Raw models come from the pass-1 bit histogram
+    # (our restatement of quantizer.py:99-110); the solve is the reference's.
+    raw_models = []
+    for i in range(len(lam32)):
+        counts = np.array([np.bincount(B32[i][:, c].astype(np.int64), minlength=N + 1) for c in range(C)])
+        raw_models.append(O.neg_log2_freq(counts, 1))
+    L4 = O.corrected_code_lengths(N, B, raw_models)
+    Zd, Bd = ref_utils.batch_quantize_indep_dims((B, C), P, L4, fun, lambs=lam32, backend=np, return_np=True)
+    # Only Z_hat is kept: the NumPy branch does `code_indices.choose(L)` on the whole 4-D
+    # length stack (utils.py:404) instead of L[i], so its num_bits output is not the
+    # per-lambda value the TF branch (utils.py:407-415) returns.
+    Zc = np.stack([Zd[l] for l in lam32])
+    save("g8_corrected_lengths.npz", raw_models=np.stack(raw_models), zhat=Zc)
+
+    # G6: exhaustive search over all 2047 sorted code points, reference quantize_indep_dims, per row.
+    rank_levels = O.levels_of_sorted_ranks(N)
+    lens_sorted = np.repeat(rank_levels[None, :], C, axis=0).astype(np.float32)
+    rows = np.arange(0, 48)
+    lam_sel = [0, 9, 16, 24, 31]
+    zh = np.empty((len(lam_sel), rows.shape[0], C), np.float32)
+    nb = np.empty((len(lam_sel), rows.shape[0], C), np.float32)
+    for a, li in enumerate(lam_sel):
+        for b, r in enumerate(rows):
+            f_row = ref_utils.curry_normal_logpdf(loc=mu[r], scale=sigma[r], ignore_const=True, backend=object())
+            z, n_ = ref_utils.quantize_indep_dims(mu[r], orc.by_channel, lens_sorted, f_row, lam32[li], backend=np)
+            zh[a, b], nb[a, b] = z, n_
+    save("g6_brute_force.npz", rows=rows, lam_idx=np.array(lam_sel), zhat=zh, bits=nb)
+
+
+# ---------------------------------------------------------------- G7 (notebook)
+def g7():
+    nb_path = os.path.join(REF, "word-embeddings", "compress-trained-word-embeddings.ipynb")
+    cells = json.load(open(nb_path))["cells"]
+    src = {i: "".join(c["source"]) for i, c in enumerate(cells) if c["cell_type"] == "code"}
+    rng = np.random.default_rng(107)
+    V, D = 250, 12
+    vecs_u = rng.normal(-0.0799, 1.2329, (V, D)).astype(np.float32)
+    stds_u = np.clip(np.exp(rng.normal(-2, 0.7, (V, D))), 1e-4, 10).astype(np.float32)
+    vecs_u[0, 0] = 40.0
+    vecs_u[0, 1] = -40.0
+    import collections
+    import scipy.stats
+    ns = dict(np=np, scipy=scipy, Counter=collections.Counter, vecs_u=vecs_u, stds_u=stds_u, print=lambda *a, **k: None)
+    for cid, must in ((25, "empirical_std"), (26, "codepoints_and_lengths"), (28, "def compress_coordinates"),
+                      (29, "def empirical_entropy")):
+        assert must in src[cid], (cid, src[cid][:80])
+        exec(src[cid], ns)
+    betas = [0.01, 0.37, 1.0, 9.5, 312.0, 1e5]
+    outs, ents = [], []
+    for beta in betas:
+        opt, _ = ns["compress_coordinates"](vecs_u, stds_u, float(beta))
+        outs.append(opt.copy())
+        ents.append(ns["empirical_entropy"](opt))
+    save("g7_notebook.npz", means=vecs_u, stds=stds_u, empirical_std=np.asarray(ns["empirical_std"]),
+         codepoints=ns["codepoints"], lengths=ns["lengths"], betas=np.array(betas),
+         optima=np.stack(outs), entropy=np.array(ents))
+
+
+if __name__ == "__main__":
+    assert os.path.isdir(REF), "reference tree not found; this script only runs in the build container"
+    g1_g2_g3()
+    g4()
+    g5_g6_g8()
+    g7()

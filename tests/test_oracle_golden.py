@@ -1,0 +1,163 @@
+"""The NumPy oracle against the golden vectors captured from the reference
+(tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+from scipy.stats import norm
+
+from oracle import vbq_oracle as O
+
+N = 10
+
+
+def test_g1_xi_grid(golden):
+    g = golden("g1_xi_grid.npz")
+    assert np.array_equal(O.dyadic_xi(int(g["N"])), g["xi"])
+    # level-major slot -> sorted rank is a bijection onto 0..T-1 and sorts xi
+    r = O.level_major_to_rank(N)
+    assert np.array_equal(np.sort(r), np.arange(2 ** (N + 1) - 1))
+    assert np.array_equal(g["xi"][np.argsort(r)], np.arange(1, 2 ** (N + 1)) / 2.0 ** (N + 1))
+    assert np.array_equal(O.levels_of_sorted_ranks(N)[r], np.concatenate([[n] * 2 ** n for n in range(N + 1)]))
+
+
+def test_g2_docstring_known_answers(golden):
+    g = golden("g2_n_bit_interval.npz")
+    for x, n, l, r in zip(g["x"], g["n"], g["left"], g["right"]):
+        assert O.get_n_bit_interval(float(x), int(n)) == (l, r)
+    assert O.get_n_bit_interval(0.4375, 2) == (0.375, 0.625)          # utils.py:31-32
+    assert O.get_n_bit_interval(0.004375, 2) == (0.125, 0.125)        # utils.py:82
+    assert O.get_n_bit_interval(0.04375, 5) == (0.015625, 0.046875)   # utils.py:83
+
+
+def test_g3_xi_intervals(golden):
+    g = golden("g3_xi_intervals.npz")
+    L, R = O.xi_intervals(g["x"], int(g["N"]))
+    assert np.array_equal(L, g["left"])
+    assert np.array_equal(R, g["right"])
+
+
+def test_g4_encode_vectorized(golden):
+    g = golden("g4_encode_vectorized.npz")
+    mu, sigma = g["mu"], g["sigma"]
+    fun = lambda z: norm.logpdf(z, loc=mu, scale=sigma)
+    for i, lamb in enumerate(g["lambs"]):
+        r = O.encode_vectorized(fun, mu, float(lamb), norm.cdf, norm.ppf, int(g["N"]))
+        assert np.array_equal(r["num_bits"], g["num_bits"][i])
+        assert np.array_equal(r["xi_hat"], g["xi_hat"][i])
+        assert np.array_equal(r["z_hat"], g["z_hat"][i])
+        assert r["score"] == g["score"][i]
+
+
+def _image_oracle(g):
+    C = g["mu"].shape[1]
+    orc = O.ChannelwiseOracle(C, int(g["N"]))
+    orc.build_code_points(O.factored_gaussian_icdf(g["ch_mean"], g["ch_std"]))
+    assert np.array_equal(orc.all_code_points, g["all_code_points"])
+    return orc
+
+
+def test_g5_batch_quantize_f32_and_f64(golden):
+    g = golden("g5_batch_quantize.npz")
+    orc = _image_oracle(g)
+    lam = g["lambdas"]
+    Z, bits = orc.compress_batch(g["mu"], g["sigma"], [np.float32(l) for l in lam], mode="f32")
+    assert np.array_equal(Z, g["zhat_f32"])
+    assert np.array_equal(bits, g["bits_f32"])
+    Z, bits = orc.compress_batch(g["mu"], g["sigma"], [float(l) for l in lam], mode="f64")
+    assert np.array_equal(Z, g["zhat_f64"])
+    assert np.array_equal(bits, g["bits_f64"])
+    # round-trip invariant of quantizer.py:136-137
+    q = O.qidx_lookup(orc.by_channel, g["zhat_f32"][7])
+    assert np.array_equal(np.take_along_axis(orc.by_channel, q, axis=1), g["zhat_f32"][7].T)
+
+
+def test_g6_algorithm1_equals_exhaustive_search(golden):
+    g5 = golden("g5_batch_quantize.npz")
+    g6 = golden("g6_brute_force.npz")
+    orc = _image_oracle(g5)
+    rows = g6["rows"]
+    lens_sorted = np.repeat(O.levels_of_sorted_ranks(N)[None], orc.C, axis=0).astype(np.float32)
+    for a, li in enumerate(g6["lam_idx"]):
+        lamb = np.float32(g5["lambdas"][li])
+        # reference exhaustive result == our exhaustive restatement
+        for b, r in enumerate(rows):
+            z, nb, _ = O.brute_force_solve(g5["mu"][r], g5["sigma"][r], orc.by_channel, lens_sorted, lamb)
+            assert np.array_equal(z, g6["zhat"][a, b])
+            assert np.array_equal(nb, g6["bits"][a, b])
+        # ... and == the 21-candidate result captured from batch_quantize_indep_dims
+        assert np.array_equal(g6["zhat"][a], g5["zhat_f32"][li][rows])
+        assert np.array_equal(g6["bits"][a].astype(np.int32), g5["bits_f32"][li][rows])
+
+
+def test_g8_corrected_lengths(golden):
+    g5 = golden("g5_batch_quantize.npz")
+    g8 = golden("g8_corrected_lengths.npz")
+    orc = _image_oracle(g5)
+    lam = [np.float32(l) for l in g5["lambdas"]]
+    (Z1, b1), (Z2, b2) = orc.build_entropy_models(g5["mu"], g5["sigma"], lam, add_n_smoothing=1)
+    assert np.array_equal(Z1, g5["zhat_f32"])
+    assert np.array_equal(np.stack([orc.raw_models[l] for l in lam]), g8["raw_models"])
+    assert np.array_equal(Z2, g8["zhat"])
+    # entropy models are proper code-length tables
+    for l in lam:
+        m = orc.entropy_models[l]
+        assert m.shape == (orc.C, orc.T) and m.dtype == np.float32
+        assert np.allclose(np.sum(2.0 ** (-m.astype(np.float64)), axis=1), 1.0, atol=1e-4)
+    out = orc.compress_latents(g5["mu"], g5["sigma"], lam)
+    assert set(out) == {"Z_hat", "raw_num_bits", "num_bits_cl", "num_bits"}
+    assert np.array_equal(out["Z_hat"][lam[3]], Z2[3])
+
+
+def test_g7_notebook(golden):
+    g = golden("g7_notebook.npz")
+    means, stds = g["means"], g["stds"]
+    es = O.empirical_std(means)
+    assert es.dtype == np.float32 and es == g["empirical_std"]
+    pts, lens = O.notebook_code_book(es, 10)
+    assert np.array_equal(pts, g["codepoints"]) and np.array_equal(lens, g["lengths"])
+    for i, beta in enumerate(g["betas"]):
+        out = O.compress_coordinates(means, stds, float(beta), pts, lens)
+        assert out.dtype == np.float32
+        assert np.array_equal(out, g["optima"][i])
+        assert O.empirical_entropy(out) == g["entropy"][i]
+
+
+def test_rank_formulation_matches_grid_search():
+    """The merged-table rank arithmetic (what the C oracle fast path and the HIP
+    kernel use) reproduces quantizer.py:65-80 at every level."""
+    rng = np.random.default_rng(5)
+    for C, scale in ((1, 1.2329), (3, 0.4)):
+        orc = O.ChannelwiseOracle(C, N)
+        orc.build_code_points(O.factored_gaussian_icdf(np.zeros(C), np.full(C, scale)))
+        t = orc.by_channel
+        z = np.concatenate([rng.normal(0, scale * 1.5, 20000), t[0][rng.integers(0, 2047, 3000)],
+                            [50, -50, t[0][0], t[0][-1], np.nextafter(t[0][-1], np.float32(9)),
+                             np.nextafter(t[0][0], np.float32(-9))]]).astype(np.float32)
+        Z = np.repeat(z[:, None], C, axis=1)
+        left, right = O.get_all_N_bit_intervals(orc.grids, Z)
+        for c in range(C):
+            assert np.all(np.diff(t[c]) > 0)
+            kl, kr = O.interval_ranks(t[c], z, N)
+            assert np.array_equal(t[c][kl - 1], left[c])
+            assert np.array_equal(t[c][kr - 1], right[c])
+            # level-major slot <-> rank
+            assert np.array_equal(t[c][O.level_major_to_rank(N)], orc.all_code_points[c])
+
+
+def test_bmshj_self_consistency():
+    rng = np.random.default_rng(3)
+    C = 5
+    mats, bias, fac = O.BMSHJ2018Oracle.init_params(C, init_scale=1.0, rng=rng)
+    fac = [f + rng.normal(0, 0.5, f.shape).astype(np.float32) for f in fac]
+    mats = [m + rng.normal(0, 0.3, m.shape).astype(np.float32) for m in mats]
+    p = O.BMSHJ2018Oracle(*O.BMSHJ2018Oracle.effective(mats, bias, fac))
+    x = np.sort(rng.normal(0, 2, (400, C)).astype(np.float32), axis=0)
+    cdf, pdf = p.cdf_pdf(x)
+    assert np.all(np.diff(cdf, axis=0) >= 0) and np.all(pdf > 0)
+    assert np.array_equal(cdf, p.cdf(x))
+    h = 1e-2
+    fd = (p.cdf(x + np.float32(h)).astype(np.float64) - p.cdf(x - np.float32(h))) / (2 * h)
+    assert np.allclose(fd, pdf, rtol=2e-2, atol=2e-4)
+    xi = np.repeat(O.dyadic_xi(6)[:, None], C, axis=1)
+    z = p.inverse_cdf(xi)
+    assert z.dtype == np.float32
+    assert np.allclose(p.cdf(z), xi, atol=2e-6)
