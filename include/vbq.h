@@ -1,0 +1,192 @@
+/*
+ * vbq.h -- C-ABI of the MI355X-native VBQ hot path (libvbq_hip.so).
+ *
+ * Boundary rules
+ *   - plain `extern "C"` functions, plain pointers and sizes; no torch / C++ types.
+ *   - every pointer named `d_*` is DEVICE memory (borrowed; e.g. tensor.data_ptr() of a
+ *     PyTorch-ROCm tensor), every pointer named `h_*` is HOST memory.
+ *   - all work is enqueued on the caller's `stream` (a hipStream_t passed as void*;
+ *     NULL = the default stream) and returns without synchronising; nothing is
+ *     allocated inside a call -- scratch comes from a caller-provided workspace.
+ *   - return value: 0 = ok, negative = VBQ_ERR_*; vbq_last_error() gives the text of
+ *     the calling thread's most recent failure.
+ *   - no global state besides that thread-local error string.
+ *
+ * The reference (mandt-lab/vbq) has no FFI of its own: the boundary it offers is the
+ * Python call surface listed in SURVEY.md 8(b).  Each entry point below names the
+ * reference code it replaces; INTEGRATION.md shows the ctypes binding a maintainer of
+ * the reference would add.
+ *
+ * Table layout ("level-major"), shared by every entry point that takes `d_table_lm`:
+ *   float table[C][T], T = 2^(N+1)-1; the 2^n code points of bit length n occupy slots
+ *   [2^n-1, 2^(n+1)-1) in increasing order.  This is exactly
+ *   ChannelwisePriorCDFQuantizer.all_code_points (img-compression/quantizer.py:30-36)
+ *   and the notebook's `codepoints` (word-embeddings/...ipynb:383-389).
+ * Quantization index ("rank index"), produced / consumed as uint16:
+ *   slot (n, i) has rank k = (2i+1) * 2^(N-n) in the merged sorted table; the index is
+ *   k-1, i.e. the position in `code_points_by_channel` (quantizer.py:37) -- the value
+ *   the reference calls `qidx` / `I` (quantizer.py:135,223) whenever the sorted table
+ *   is strictly increasing.  Bit length of index q is N - ctz(q+1).
+ * Element layout:
+ *   VBQ_LAYOUT_BC  channel-last  [n_rows][n_ch]   (quantizer.py:90-91,196-197)
+ *   VBQ_LAYOUT_CB  channel-major [n_ch][n_rows]   (the reference's own C x B view, :73)
+ *   Outputs with a lambda axis are [n_lambda][...same layout as the input...].
+ */
+#ifndef VBQ_H_
+#define VBQ_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VBQ_ABI_VERSION 1
+
+enum {
+    VBQ_OK = 0,
+    VBQ_ERR_INVALID_ARGUMENT = -1,
+    VBQ_ERR_UNSUPPORTED = -2,
+    VBQ_ERR_LAUNCH = -3,
+    VBQ_ERR_WORKSPACE = -4
+};
+
+enum { VBQ_LAYOUT_BC = 0, VBQ_LAYOUT_CB = 1 };
+
+/* Tie-break / arithmetic of the solve. */
+enum {
+    /* TF-eager path of the image pipeline: every op rounded to f32, candidate order
+     * [L_0..L_N, R_1..R_N], first maximum wins (utils.py:319-320,388-401;
+     * quantizer.py:183). */
+    VBQ_MODE_F32 = 0,
+    /* NumPy backend exactly as written: f32 distortion, lambda*len and the score in
+     * f64 (utils.py:388 leaves integer lengths uncast for backend=np). */
+    VBQ_MODE_F64_SCORE = 1
+};
+
+int vbq_abi_version(void);
+const char *vbq_last_error(void);
+
+/* Number of GPUs visible / name of device `dev` (for harness output only). */
+int vbq_device_count(void);
+int vbq_device_name(int dev, char *buf, size_t buflen);
+
+/* ----------------------------------------------------------------------------------
+ * K1  R-D solve.  Replaces, in one pass over (mu, sigma):
+ *       ChannelwisePriorCDFQuantizer.get_all_N_bit_intervals   quantizer.py:65-80
+ *       ChannelwisePriorCDFQuantizer.compress_batch_channel_latents  quantizer.py:156-188
+ *       utils.curry_normal_logpdf(ignore_const=True)           utils.py:307-321
+ *       utils.batch_quantize_indep_dims                        utils.py:363-423
+ *       the qidx lookup                                        quantizer.py:135,223
+ *     for all `n_lambda` trade-offs at once (the reference also shares the distortions
+ *     across lambdas, utils.py:387,392).
+ *
+ *   d_mu, d_sigma   f32, n_rows*n_ch elements in `layout`; sigma > 0, all finite.
+ *   d_table_lm      f32 [n_ch][T] level-major, non-decreasing in xi for every channel.
+ *   d_level_len     f32 [n_lambda][n_ch][N+1] code length of bit-level n (the
+ *                   "n + overhead" of quantizer.py:171-175), or NULL for the raw
+ *                   lengths n (quantizer.py:167-169).
+ *   h_lambdas       HOST doubles [n_lambda]; VBQ_MODE_F32 rounds each to f32 first
+ *                   (TF casts the Python scalar to the tensor dtype).
+ *   d_out_idx       u16 [n_lambda][n_rows*n_ch] rank index of the winner.
+ *   d_out_zhat      optional f32, same shape: the winning code point (Z_hat).
+ *   d_out_bits      optional f32, same shape: its code length (num_bits).
+ *   d_workspace     vbq_quantize_workspace_bytes() bytes of device scratch.
+ * ---------------------------------------------------------------------------------- */
+size_t vbq_quantize_workspace_bytes(int32_t n_ch, int32_t n_lambda, int32_t N);
+
+int vbq_quantize_f32(const float *d_mu, const float *d_sigma, int64_t n_rows, int32_t n_ch,
+                     int32_t layout, const float *d_table_lm, const float *d_level_len,
+                     const double *h_lambdas, int32_t n_lambda, int32_t N, int32_t mode,
+                     uint16_t *d_out_idx, float *d_out_zhat, float *d_out_bits,
+                     void *d_workspace, size_t workspace_bytes, void *stream);
+
+/* ----------------------------------------------------------------------------------
+ * K1c  Generic candidate solve.  Replaces utils.batch_quantize_indep_dims
+ *      (img-compression/utils.py:363-423) for caller-built candidates, i.e. its
+ *      "3D tensor of M x B x K" form (:367-370), and -- with n_lambda = 1 and the sorted
+ *      table broadcast by the caller -- utils.quantize_indep_dims (:330-360).
+ *   d_P     f32 [M][n_elems] candidate code points (n_elems = B*K flattened).
+ *   d_len   f32 [M][n_elems], or [n_lambda][M][n_elems] when len_per_lambda != 0
+ *           (the 4-D stack of utils.py:393-394).
+ *   d_out_j   optional u8  [n_lambda][n_elems] winning candidate (first maximum);
+ *   d_out_zhat / d_out_bits   optional f32 [n_lambda][n_elems]   (utils.py:414-415).
+ * ---------------------------------------------------------------------------------- */
+int vbq_argmax_candidates_f32(const float *d_P, const float *d_len, int32_t len_per_lambda,
+                              const float *d_mu, const float *d_sigma, int64_t n_elems,
+                              const double *h_lambdas, int32_t n_lambda, int32_t M, int32_t mode,
+                              uint8_t *d_out_j, float *d_out_zhat, float *d_out_bits, void *stream);
+
+/* ----------------------------------------------------------------------------------
+ * K1n  Notebook solve.  Replaces compress_coordinates(means, stds, beta, bitlengths)
+ *      (word-embeddings/compress-trained-word-embeddings.ipynb:429-443): f64 squared
+ *      error against an f64 code book, penalty (2*beta)*sigma^2 rounded to f32 and
+ *      multiplied by the integer length, first minimum in level-major order; one
+ *      shared code book.  Output values are the code points rounded to f32 (the
+ *      notebook stores into empty_like(means)).
+ *   d_codebook_lm   f64 [T] level-major (ipynb:383-389), non-decreasing in xi.
+ *   h_betas         HOST doubles [n_beta].
+ *   d_out_idx       u16 [n_beta][n] rank index;  d_out_val optional f32 [n_beta][n].
+ * ---------------------------------------------------------------------------------- */
+int vbq_quantize_notebook_f64(const float *d_means, const float *d_stds, int64_t n,
+                              const double *d_codebook_lm, const double *h_betas, int32_t n_beta,
+                              int32_t N, uint16_t *d_out_idx, float *d_out_val, void *stream);
+
+/* ----------------------------------------------------------------------------------
+ * K2  Histogram pass.  Replaces the per-channel np.bincount of quantizer.py:104-105
+ *     and :138-140 and the Counter of ipynb:453.  counts[l][c][q] += #{elements of
+ *     channel c with index q under lambda l}.  Counts are ADDED to d_counts (zero it
+ *     first for a fresh histogram); int64 so that 1e9-element shards cannot overflow.
+ *     The bit-length histogram of :104 is the same array summed over the ranks of each
+ *     level (level = N - ctz(q+1)).
+ * ---------------------------------------------------------------------------------- */
+int vbq_histogram_u16(const uint16_t *d_idx, int64_t n_rows, int32_t n_ch, int32_t layout,
+                      int32_t n_lambda, int32_t N, int64_t *d_counts, void *stream);
+
+/* ----------------------------------------------------------------------------------
+ * K3  Moment pass.  Replaces empirical_std = sqrt(mean(mu^2)) (ipynb:373-374) and the
+ *     per-channel mean/std a FactoredGaussianPrior needs (vae_models.py:32-35).
+ *     d_out[c] = { sum x, sum x^2 } accumulated in f64 (ADDED to d_out).
+ * ---------------------------------------------------------------------------------- */
+int vbq_moments_f32(const float *d_x, int64_t n_rows, int32_t n_ch, int32_t layout,
+                    double *d_out /* [n_ch][2] */, void *stream);
+
+/* ----------------------------------------------------------------------------------
+ * Table lookup by rank index: out[l][e] = tab[(l)][c(e)][idx[l][e]].  Replaces
+ *   tf.gather(entropy_model, I, batch_dims=1)            quantizer.py:226-228
+ *   tf.gather(code_points_by_channel, qidx, batch_dims=1) quantizer.py:136
+ *   d_tab   f32 [n_lambda][n_ch][T] when tab_per_lambda != 0, else [n_ch][T];
+ *           indexed by rank (i.e. a SORTED table such as code_points_by_channel).
+ * ---------------------------------------------------------------------------------- */
+int vbq_gather_f32(const uint16_t *d_idx, int64_t n_rows, int32_t n_ch, int32_t layout,
+                   int32_t n_lambda, int32_t N, const float *d_tab, int32_t tab_per_lambda,
+                   float *d_out, void *stream);
+
+/* ----------------------------------------------------------------------------------
+ * K4  BMSHJ2018 prior (learned_prior.py).  Parameters are the EFFECTIVE ones --
+ *     softplus(matrix_i), bias_i, tanh(factor_i) -- packed per channel as
+ *       [ M0(3x1) b0(3) f0(3) | M1(3x3) b1(3) f1(3) | M2(3x3) b2(3) f2(3) | M3(1x3) b3(1) ]
+ *     = 43 floats (dims = (3,3,3), learned_prior.py:11,30-57), row-major matrices.
+ *   vbq_bmshj_cdf_pdf_f32   cdf / analytic pdf / log(pdf+1e-10) at x
+ *                           (learned_prior.py:70-148, 235-242, 244-334); any of the
+ *                           three outputs may be NULL.  x is [n_rows][n_ch] channel-last.
+ *   vbq_bmshj_icdf_step_f32 one masked bisection update of learned_prior.py:199-209 on
+ *                           [n_rows][n_ch] brackets; writes mid points and accumulates
+ *                           d_flags[0] = #(f(mid) != 0), d_flags[1] = bits of the minimum
+ *                           bracket width (as u32 of a non-negative float) so that the
+ *                           host can apply the global stopping rule of :210-211.
+ * ---------------------------------------------------------------------------------- */
+#define VBQ_BMSHJ_PARAMS_PER_CHANNEL 43
+
+int vbq_bmshj_cdf_pdf_f32(const float *d_params, const float *d_x, int64_t n_rows, int32_t n_ch,
+                          float *d_cdf, float *d_pdf, float *d_logpdf, void *stream);
+
+int vbq_bmshj_icdf_step_f32(const float *d_params, const float *d_xi, int64_t n_rows, int32_t n_ch,
+                            float *d_left, float *d_right, float *d_mid, uint32_t *d_flags,
+                            void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VBQ_H_ */

@@ -1,0 +1,186 @@
+/*
+ * vbq_oracle.c -- CPU restatement of the VBQ hot path in plain C.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Loaded by tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py; never by the product package vbq_amd.
+ *
+ * It follows the reference formulation, not the GPU kernel's: every bit level is searched
+ * separately with a lower bound on that level's own points and the result is pushed
+ * through the index arithmetic of the edge-padded search grids
+ *   (img-compression/quantizer.py:50-63 grids, :65-80 search + clip),
+ * the 2N+1 candidates are scored in the order [L_0..L_N, R_1..R_N] (quantizer.py:183)
+ * with  -0.5*((P-mu)/sigma)**2 - lambda*len  as separately rounded f32 operations
+ * (img-compression/utils.py:319-320, 388-396) and the FIRST maximum wins (utils.py:401).
+ * Build with -ffp-contract=off (see Makefile) so that no a*b+c is fused.
+ *
+ * Pinning: tests/test_oracle_c.py checks this file against the golden vectors captured
+ * from the reference (tests/golden/g5, g6, g7, g8) and against oracle/vbq_oracle.py.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define MAXN 15
+
+static inline int64_t elem_offset(int64_t row, int32_t c, int64_t n_rows, int32_t n_ch, int32_t layout) {
+    return layout == 0 ? row * (int64_t)n_ch + c : (int64_t)c * n_rows + row;
+}
+
+/* first i in [0, m] with p[i] >= z  (np/tf searchsorted side='left') */
+static inline int lower_bound_f32(const float *p, int m, float z) {
+    int lo = 0, hi = m;
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if (p[mid] < z) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+/* positions (within level n) of the left/right endpoint the reference's padded grid yields */
+static inline void level_endpoints(const float *lvl, int n, int N, float z, int *lpos, int *rpos) {
+    const int m = 1 << n;
+    if (n == 0) { *lpos = *rpos = 0; return; }                 /* quantizer.py:54-55: grid is one value */
+    const int G = 1 << N;
+    const int pad = (1 << (N - 1)) - (1 << (n - 1));            /* quantizer.py:57 */
+    const int i = lower_bound_f32(lvl, m, z);
+    int g;                                                       /* lower bound inside the padded grid */
+    if (i == 0) g = 0;                                           /* z <= first point: hits the left padding */
+    else if (i == m) g = G;                                      /* beyond everything */
+    else g = pad + i;
+    if (g > G - 1) g = G - 1;                                    /* quantizer.py:75 */
+    int gl = g - 1; if (gl < 0) gl = 0;                          /* quantizer.py:76 */
+    int r = g - pad;  if (r < 0) r = 0;  if (r > m - 1) r = m - 1;
+    int l = gl - pad; if (l < 0) l = 0;  if (l > m - 1) l = m - 1;
+    *lpos = l; *rpos = r;
+}
+
+int vbq_oracle_quantize_f32(const float *mu, const float *sigma, int64_t n_rows, int32_t n_ch, int32_t layout,
+                            const float *table_lm, const float *level_len, const double *lambdas, int32_t L,
+                            int32_t N, int32_t mode, uint16_t *out_idx, float *out_zhat, float *out_bits,
+                            int32_t n_threads) {
+    if (N < 1 || N > MAXN || n_ch < 1 || L < 1) return -1;
+    const int T = (2 << N) - 1, N1 = N + 1, M = 2 * N + 1;
+    const int64_t E = n_rows * (int64_t)n_ch;
+#ifdef _OPENMP
+    if (n_threads > 0) omp_set_num_threads(n_threads);
+#endif
+#pragma omp parallel for schedule(static)
+    for (int64_t row = 0; row < n_rows; ++row) {
+        for (int32_t c = 0; c < n_ch; ++c) {
+            const int64_t e = elem_offset(row, c, n_rows, n_ch, layout);
+            const float z = mu[e], s = sigma[e];
+            const float *tb = table_lm + (int64_t)c * T;
+            float P[2 * MAXN + 1], D[2 * MAXN + 1];
+            int pos[2 * MAXN + 1], lev[2 * MAXN + 1];
+            for (int n = 0; n <= N; ++n) {
+                int lp, rp;
+                level_endpoints(tb + ((1 << n) - 1), n, N, z, &lp, &rp);
+                P[n] = tb[(1 << n) - 1 + lp]; pos[n] = lp; lev[n] = n;
+                if (n >= 1) { P[N + n] = tb[(1 << n) - 1 + rp]; pos[N + n] = rp; lev[N + n] = n; }
+            }
+            for (int j = 0; j < M; ++j) {                         /* utils.py:319-320 */
+                volatile float d = P[j] - z;
+                volatile float t = d / s;
+                volatile float q = t * t;
+                D[j] = -0.5f * q;
+            }
+            for (int l = 0; l < L; ++l) {
+                const float *ll = level_len ? level_len + ((int64_t)l * n_ch + c) * N1 : NULL;
+                int bj = 0;
+                if (mode == 0) {
+                    const float lam = (float)lambdas[l];
+                    float best = 0.f;
+                    for (int j = 0; j < M; ++j) {
+                        const float len = ll ? ll[lev[j]] : (float)lev[j];
+                        volatile float pen = lam * len;
+                        volatile float sc = D[j] - pen;
+                        if (j == 0 || sc > best) { best = sc; bj = j; }
+                    }
+                } else {
+                    const double lam = lambdas[l];
+                    double best = 0.0;
+                    for (int j = 0; j < M; ++j) {
+                        const double len = ll ? (double)ll[lev[j]] : (double)lev[j];
+                        volatile double pen = lam * len;
+                        volatile double sc = (double)D[j] - pen;
+                        if (j == 0 || sc > best) { best = sc; bj = j; }
+                    }
+                }
+                const int64_t o = (int64_t)l * E + e;
+                out_idx[o] = (uint16_t)((((2 * pos[bj] + 1)) << (N - lev[bj])) - 1);
+                if (out_zhat) out_zhat[o] = P[bj];
+                if (out_bits) out_bits[o] = ll ? ll[lev[bj]] : (float)lev[bj];
+            }
+        }
+    }
+    return 0;
+}
+
+/* ipynb:429-443, literally: every code point of the level-major code book is scored in f64,
+ * penalty (2*beta)*sigma^2 held in f32 (NumPy-1.17 casting) times the integer length,
+ * first minimum wins.  out_slot = winning level-major slot. */
+int vbq_oracle_compress_coordinates(const float *means, const float *stds, int64_t n, const double *codebook,
+                                    const int64_t *lengths, int32_t T, double beta, float *out_val,
+                                    int32_t *out_slot, int32_t n_threads) {
+#ifdef _OPENMP
+    if (n_threads > 0) omp_set_num_threads(n_threads);
+#endif
+    const float tb = (float)(2.0 * beta);
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) {
+        const double z = (double)means[i];
+        volatile float var = stds[i] * stds[i];
+        volatile float w32 = tb * var;
+        const double w = (double)w32;
+        double best = 0.0; int bj = 0;
+        for (int j = 0; j < T; ++j) {
+            volatile double d = codebook[j] - z;
+            volatile double err = d * d;
+            volatile double pen = w * (double)lengths[j];
+            volatile double cost = err + pen;
+            if (j == 0 || cost < best) { best = cost; bj = j; }
+        }
+        if (out_val) out_val[i] = (float)codebook[bj];
+        if (out_slot) out_slot[i] = bj;
+    }
+    return 0;
+}
+
+/* quantizer.py:104-105,138-140: per-(lambda, channel) bincount of rank indices */
+int vbq_oracle_histogram(const uint16_t *idx, int64_t n_rows, int32_t n_ch, int32_t layout, int32_t L, int32_t N,
+                         int64_t *counts) {
+    const int T = (2 << N) - 1;
+    const int64_t E = n_rows * (int64_t)n_ch;
+    for (int l = 0; l < L; ++l)
+        for (int64_t row = 0; row < n_rows; ++row)
+            for (int32_t c = 0; c < n_ch; ++c) {
+                const int64_t e = elem_offset(row, c, n_rows, n_ch, layout);
+                counts[((int64_t)l * n_ch + c) * T + idx[(int64_t)l * E + e]] += 1;
+            }
+    return 0;
+}
+
+/* f64 sums of x and x^2 per channel */
+int vbq_oracle_moments(const float *x, int64_t n_rows, int32_t n_ch, int32_t layout, double *out) {
+    for (int32_t c = 0; c < n_ch; ++c) {
+        long double s1 = 0, s2 = 0;
+        for (int64_t row = 0; row < n_rows; ++row) {
+            const double v = x[elem_offset(row, c, n_rows, n_ch, layout)];
+            s1 += v; s2 += v * v;
+        }
+        out[2 * c] = (double)s1; out[2 * c + 1] = (double)s2;
+    }
+    return 0;
+}
+
+int vbq_oracle_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

@@ -1,0 +1,248 @@
+"""Parity of the HIP path (through the C-ABI, via vbq_amd.ops) with the oracle and the golden
+vectors captured from the reference.  Integer / index outputs must be bit-identical."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from oracle import c_oracle as CO
+from oracle import vbq_oracle as O
+
+pytestmark = pytest.mark.gpu
+N = 10
+T = 2047
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.fail("gpu-marked test run without a ROCm device")
+    from vbq_amd import ops as _ops
+    return _ops
+
+
+def dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a)).cuda()
+
+
+def host(t):
+    return t.cpu().numpy()
+
+
+def sorted_tables(all_pts):
+    r = O.level_major_to_rank(N)
+    s = np.empty_like(all_pts)
+    s[:, r] = all_pts
+    return s
+
+
+# ------------------------------------------------------------------ golden vectors (reference outputs)
+@pytest.mark.parametrize("mode,zk,bk", [("f32", "zhat_f32", "bits_f32"), ("f64", "zhat_f64", "bits_f64")])
+def test_quantize_golden_g5(ops, golden, mode, zk, bk):
+    g = golden("g5_batch_quantize.npz")
+    idx, zh, bt = ops.quantize(dev(g["mu"]), dev(g["sigma"]), dev(g["all_code_points"]), list(g["lambdas"]), N=N,
+                               mode=mode, want_zhat=True, want_bits=True)
+    assert np.array_equal(host(zh), g[zk])
+    assert np.array_equal(host(bt).astype(np.int32), g[bk])
+    srt = sorted_tables(g["all_code_points"])
+    q = host(idx).astype(np.int64)
+    for l in range(q.shape[0]):
+        assert np.array_equal(np.take_along_axis(srt, q[l].T, axis=1).T, g[zk][l])      # quantizer.py:136-137
+    # channel-major layout of the same data takes the FLAT kernel: same answers
+    idx_cb = ops.quantize(dev(g["mu"].T), dev(g["sigma"].T), dev(g["all_code_points"]), list(g["lambdas"]), N=N,
+                          mode=mode, layout="cb")
+    assert np.array_equal(host(idx_cb).transpose(0, 2, 1), host(idx))
+
+
+def test_quantize_golden_g8_corrected_lengths(ops, golden):
+    g5, g8 = golden("g5_batch_quantize.npz"), golden("g8_corrected_lengths.npz")
+    level_len = np.stack([O.corrected_level_lengths(N, m).T for m in g8["raw_models"]])
+    for layout in ("bc", "cb"):
+        mu, sg = (g5["mu"], g5["sigma"]) if layout == "bc" else (g5["mu"].T, g5["sigma"].T)
+        idx, zh, bt = ops.quantize(dev(mu), dev(sg), dev(g5["all_code_points"]), list(g5["lambdas"]), N=N,
+                                   level_len=dev(level_len), layout=layout, want_zhat=True, want_bits=True)
+        zh, bt, idx = host(zh), host(bt), host(idx)
+        if layout == "cb":
+            zh, bt, idx = zh.transpose(0, 2, 1), bt.transpose(0, 2, 1), idx.transpose(0, 2, 1)
+        assert np.array_equal(zh, g8["zhat"])
+        lev = O.levels_of_sorted_ranks(N)[idx]
+        want = np.take_along_axis(level_len[:, None], lev[..., None].astype(np.int64), axis=3)[..., 0]
+        assert np.array_equal(bt, want)
+
+
+def test_notebook_golden_g7(ops, golden):
+    g = golden("g7_notebook.npz")
+    idx, val = ops.quantize_notebook(dev(g["means"]), dev(g["stds"]), dev(g["codepoints"]), list(g["betas"]), N=N)
+    assert np.array_equal(host(val), g["optima"])
+    cnt = host(ops.histogram(idx.reshape(len(g["betas"]), -1), 1, N=N))
+    for i in range(len(g["betas"])):
+        assert O.entropy_from_counts(cnt[i, 0]) == pytest.approx(g["entropy"][i], rel=1e-12)
+
+
+def test_argmax_candidates_golden_g5(ops, golden):
+    g = golden("g5_batch_quantize.npz")
+    orc = O.ChannelwiseOracle(g["mu"].shape[1], N)
+    orc.build_code_points(O.factored_gaussian_icdf(g["ch_mean"], g["ch_std"]))
+    left, right = O.get_all_N_bit_intervals(orc.grids, g["mu"])
+    P = O.assemble_candidates(left, right)
+    Lraw = O.raw_code_lengths(N, *g["mu"].shape).astype(np.float32)
+    for mode, zk, bk in (("f32", "zhat_f32", "bits_f32"), ("f64", "zhat_f64", "bits_f64")):
+        zh, bt = ops.argmax_candidates(dev(P), dev(Lraw), dev(g["mu"]), dev(g["sigma"]), list(g["lambdas"]), mode=mode)
+        assert np.array_equal(host(zh), g[zk])
+        assert np.array_equal(host(bt).astype(np.int32), g[bk])
+
+
+# ------------------------------------------------------------------ seeded inputs vs the C oracle
+def synth(rng, rows, C):
+    scale = np.exp(rng.uniform(np.log(0.3), np.log(3.0), C))
+    orc = O.ChannelwiseOracle(C, N)
+    orc.build_code_points(O.factored_gaussian_icdf(np.zeros(C), scale))
+    mu = (scale * rng.normal(0, 1.0, (rows, C))).astype(np.float32)
+    sg = np.clip(np.exp(rng.normal(-2, 0.7, (rows, C))), 1e-4, 10).astype(np.float32)
+    return orc.all_code_points, mu, sg
+
+
+LAM32 = list(2.0 ** np.linspace(-8, 7.5, 32))
+
+
+@pytest.mark.parametrize("rows,C", [(1, 1), (3, 1), (1021, 1), (4096, 1), (100003, 1), (777, 2), (130, 16), (257, 17),
+                                    (1536, 32), (300, 48)])
+def test_quantize_vs_oracle_shapes(ops, rows, C):
+    rng = np.random.default_rng(rows * 31 + C)
+    tab, mu, sg = synth(rng, rows, C)
+    lam = LAM32 if rows * C < 60000 else LAM32[::5]
+    want = CO.quantize(mu, sg, tab, lam, N=N, threads=8)
+    got = ops.quantize(dev(mu), dev(sg), dev(tab), lam, N=N)
+    assert got.shape == (len(lam), rows, C)
+    assert np.array_equal(host(got), want)
+    if C > 1:
+        got_cb = ops.quantize(dev(mu.T), dev(sg.T), dev(tab), lam, N=N, layout="cb")
+        assert np.array_equal(host(got_cb).transpose(0, 2, 1), want)
+
+
+def test_quantize_edge_inputs(ops):
+    rng = np.random.default_rng(77)
+    tab, mu, sg = synth(rng, 4096, 1)
+    srt = np.sort(tab[0])
+    mu = mu.ravel()
+    mu[:2047] = srt                                   # exact code-point hits
+    mu[2047:2047 + 1000] = np.nextafter(srt[:1000], np.float32(np.inf))
+    mu[3047:3050] = [1e30, -1e30, 0.0]
+    mu[3050:3060] = 0.5 * (srt[1000:1010] + srt[1001:1011])   # midpoints: exact L/R ties
+    sg = sg.ravel()
+    sg[3060:3070] = 1e-4
+    sg[3070:3080] = 10.0
+    sg[3080:3090] = np.float32(2.0) - np.float32(2.0 ** -23)   # all-ones mantissa
+    want = CO.quantize(mu, sg, tab, LAM32, N=N)
+    got = ops.quantize(dev(mu), dev(sg), dev(tab), LAM32, N=N)
+    assert np.array_equal(host(got), want[:, :, 0])
+    # empty input and more than one lambda chunk (> 32 lambdas)
+    e = ops.quantize(dev(mu[:0]), dev(sg[:0]), dev(tab), LAM32, N=N)
+    assert e.shape == (32, 0)
+    lam70 = list(np.exp(np.linspace(np.log(0.01), np.log(1e5), 70)))
+    assert np.array_equal(host(ops.quantize(dev(mu), dev(sg), dev(tab), lam70, N=N)),
+                          CO.quantize(mu, sg, tab, lam70, N=N)[:, :, 0])
+
+
+def test_quantize_duplicate_code_points(ops):
+    """f32 tables with repeated values (hard part 4): indices still address equal values and
+    the candidate semantics still match the per-level search of the reference."""
+    rng = np.random.default_rng(5)
+    xi = O.dyadic_xi(N)
+    from scipy.stats import norm
+    pts = np.round(norm.ppf(xi) * 64) / 64             # heavy duplication, still non-decreasing in xi
+    tab = pts.astype(np.float32)[None]
+    mu = rng.normal(0, 1.2, 5000).astype(np.float32)
+    sg = np.exp(rng.normal(-2, 0.7, 5000)).astype(np.float32)
+    want_i, want_z = CO.quantize(mu, sg, tab, LAM32, N=N, want_zhat=True)
+    got_i, got_z = ops.quantize(dev(mu), dev(sg), dev(tab), LAM32, N=N, want_zhat=True)
+    assert np.array_equal(host(got_z), want_z[:, :, 0])
+    assert np.array_equal(host(got_i), want_i[:, :, 0])
+
+
+@pytest.mark.parametrize("Nbits", [4, 6, 8])
+def test_quantize_other_bit_depths(ops, Nbits):
+    rng = np.random.default_rng(Nbits)
+    orc = O.ChannelwiseOracle(2, Nbits)
+    orc.build_code_points(O.factored_gaussian_icdf(np.zeros(2), np.array([1.0, 0.5])))
+    mu = rng.normal(0, 1, (500, 2)).astype(np.float32)
+    sg = np.exp(rng.normal(-2, 0.7, (500, 2))).astype(np.float32)
+    want = CO.quantize(mu, sg, orc.all_code_points, LAM32[::4], N=Nbits)
+    got = ops.quantize(dev(mu), dev(sg), dev(orc.all_code_points), LAM32[::4], N=Nbits)
+    assert np.array_equal(host(got), want)
+
+
+def test_notebook_vs_oracle(ops):
+    rng = np.random.default_rng(9)
+    means = rng.normal(-0.08, 1.23, (999, 7)).astype(np.float32)
+    stds = np.exp(rng.normal(-2, 0.7, (999, 7))).astype(np.float32)
+    pts, lens = O.notebook_code_book(O.empirical_std(means), N)
+    betas = [0.01, 0.5, 3.0, 100.0, 1e5]
+    idx, val = ops.quantize_notebook(dev(means), dev(stds), dev(pts), betas, N=N)
+    rank_of_slot = O.level_major_to_rank(N)
+    for i, b in enumerate(betas):
+        v, slot = CO.compress_coordinates(means, stds, b, pts, lens, threads=8)
+        assert np.array_equal(host(val)[i], v)
+        assert np.array_equal(host(idx)[i].astype(np.int64), rank_of_slot[slot])
+
+
+def test_histogram_moments_gather(ops):
+    rng = np.random.default_rng(4)
+    for rows, C in ((5000, 1), (8192, 1), (1000, 3), (300, 16), (999, 40)):
+        idx = rng.integers(0, T, (3, rows, C)).astype(np.uint16)
+        idx[2] = 1023                                       # collapsed distribution (large lambda)
+        want = CO.histogram(idx, C, N=N)
+        assert np.array_equal(host(ops.histogram(dev(idx), C, N=N)), want)
+        got_cb = ops.histogram(dev(idx.transpose(0, 2, 1)), C, N=N, layout="cb")
+        assert np.array_equal(host(got_cb), want)
+        x = rng.normal(0.3, 2.0, (rows, C)).astype(np.float32)
+        m = host(ops.moments(dev(x)))
+        ref = CO.moments(x, C)
+        assert np.allclose(m, ref, rtol=1e-12, atol=1e-9)
+        assert np.allclose(host(ops.moments(dev(x.T), layout="cb")), ref, rtol=1e-12, atol=1e-9)
+        tab = rng.normal(0, 1, (3, C, T)).astype(np.float32)
+        g = host(ops.gather(dev(idx), dev(tab), C, N=N))
+        want_g = np.take_along_axis(tab.transpose(0, 2, 1)[:, None], idx[:, :, None, :].astype(np.int64), axis=2)
+        assert np.array_equal(g, np.take_along_axis(np.broadcast_to(tab.transpose(0, 2, 1)[:, None], (3, rows, T, C)),
+                                                    idx[:, :, None, :].astype(np.int64), axis=2)[:, :, 0, :])
+        g2 = host(ops.gather(dev(idx), dev(tab[0]), C, N=N))
+        assert np.array_equal(g2[1], tab[0].T[idx[1].astype(np.int64), np.arange(C)[None, :]])
+
+
+def test_bmshj_vs_oracle(ops):
+    rng = np.random.default_rng(3)
+    C = 6
+    mats, bias, fac = O.BMSHJ2018Oracle.init_params(C, init_scale=1.0, rng=rng)
+    fac = [f + rng.normal(0, 0.5, f.shape).astype(np.float32) for f in fac]
+    mats = [m + rng.normal(0, 0.3, m.shape).astype(np.float32) for m in mats]
+    eff = O.BMSHJ2018Oracle.effective(mats, bias, fac)
+    p = O.BMSHJ2018Oracle(*eff)
+    from vbq_amd.priors import pack_bmshj_params
+    params = dev(pack_bmshj_params(*eff))
+    x = rng.normal(0, 2, (300, C)).astype(np.float32)
+    cdf, pdf, logpdf = ops.bmshj_cdf_pdf(params, dev(x), logpdf=True)
+    rc, rp = p.cdf_pdf(x)
+    assert np.allclose(host(cdf), rc, rtol=2e-6, atol=2e-7)
+    assert np.allclose(host(pdf), rp, rtol=2e-5, atol=1e-8)
+    assert np.allclose(host(logpdf), p.logpdf(x), rtol=1e-5, atol=1e-5)
+
+
+def test_large_roundtrip_properties(ops):
+    """BASELINE-size check through size-independent properties: table[idx] reproduces zhat,
+    level(idx) reproduces bits, histogram totals equal the element count, lambda-monotone rate."""
+    rng = np.random.default_rng(1)
+    rows, C = 36864, 32
+    tab, mu, sg = synth(rng, rows, C)
+    d_tab = dev(tab)
+    idx, zh, bt = ops.quantize(dev(mu), dev(sg), d_tab, LAM32, N=N, want_zhat=True, want_bits=True)
+    srt = dev(sorted_tables(tab))
+    assert torch.equal(ops.gather(idx, srt, C, N=N), zh)
+    lev = torch.as_tensor(O.levels_of_sorted_ranks(N).astype(np.float32)).cuda()
+    assert torch.equal(lev[idx.to(torch.int64)], bt)
+    cnt = ops.histogram(idx, C, N=N)
+    assert torch.all(cnt.sum(dim=2) == rows)
+    rate = bt.sum(dim=(1, 2)).cpu().numpy()
+    assert np.all(np.diff(rate) <= 0)
+    # spot-check 2 lambdas against the oracle at full size
+    want = CO.quantize(mu, sg, tab, [LAM32[3], LAM32[20]], N=N, threads=8)
+    assert np.array_equal(host(idx[[3, 20]]), want)

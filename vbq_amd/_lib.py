@@ -1,0 +1,85 @@
+"""ctypes binding of libvbq_hip.so (include/vbq.h).  No CPU fallback exists: if the
+library is missing or fails to load, every op raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from . import build as _build
+
+_LIB = None
+
+c_f32p = C.c_void_p      # device pointers travel as integers
+c_u16p = C.c_void_p
+
+OK = 0
+LAYOUT_BC, LAYOUT_CB = 0, 1
+MODE_F32, MODE_F64_SCORE = 0, 1
+BMSHJ_PARAMS_PER_CHANNEL = 43
+
+# name -> (restype, argtypes); mirrors include/vbq.h one to one (tests/test_abi.py checks it)
+SIGNATURES = {
+    "vbq_abi_version": (C.c_int, []),
+    "vbq_last_error": (C.c_char_p, []),
+    "vbq_device_count": (C.c_int, []),
+    "vbq_device_name": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t]),
+    "vbq_quantize_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
+    "vbq_quantize_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                   C.POINTER(C.c_double), C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "vbq_quantize_notebook_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_double),
+                                            C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vbq_histogram_u16": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
+                                    C.c_void_p]),
+    "vbq_moments_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "vbq_gather_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
+                                 C.c_int32, C.c_void_p, C.c_void_p]),
+    "vbq_argmax_candidates_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64,
+                                            C.POINTER(C.c_double), C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
+                                            C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vbq_bmshj_cdf_pdf_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_void_p]),
+    "vbq_bmshj_icdf_step_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_void_p]),
+}
+
+
+class VBQError(RuntimeError):
+    pass
+
+
+def library_path() -> str:
+    return os.environ.get("VBQ_HIP_LIBRARY", _build.LIB)
+
+
+def lib():
+    """Load (once) and return the ctypes handle.  Raises VBQError when the HIP extension has
+    not been built -- there is deliberately no slower path to fall back to."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise VBQError(f"HIP extension not built: {path} is missing. Run `python -m vbq_amd.build` "
+                       "(needs hipcc; cross-compiles gfx950 without a GPU).")
+    try:
+        h = C.CDLL(path)
+    except OSError as e:
+        raise VBQError(f"cannot load {path}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(h, name)
+        except AttributeError as e:
+            raise VBQError(f"{path} does not export {name}; rebuild with `python -m vbq_amd.build --force`") from e
+        fn.restype = res
+        fn.argtypes = args
+    if h.vbq_abi_version() != 1:
+        raise VBQError(f"{path}: ABI version {h.vbq_abi_version()} != 1")
+    _LIB = h
+    return h
+
+
+def check(status: int, what: str):
+    if status != OK:
+        msg = lib().vbq_last_error().decode("utf-8", "replace")
+        raise VBQError(f"{what} failed ({status}): {msg}")

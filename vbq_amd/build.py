@@ -1,0 +1,72 @@
+"""Build the HIP extension (and, for tests only, the C oracle) in-tree.
+
+    python -m vbq_amd.build            # libvbq_hip.so for gfx950
+    python -m vbq_amd.build --oracle   # also oracle/_build/libvbq_oracle.so
+
+hipcc cross-compiles gfx950 without a GPU; the resulting .so is git-ignored but travels
+with the working tree to the GPU box.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+LIBDIR = os.path.join(PKG, "lib")
+LIB = os.path.join(LIBDIR, "libvbq_hip.so")
+INCLUDE = os.path.join(ROOT, "include")
+HIP_SOURCES = ["vbq_api.hip", "vbq_quantize.hip", "vbq_hist.hip", "vbq_notebook.hip", "vbq_bmshj.hip",
+               "vbq_candidates.hip"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+               # every f32/f64 op of the reference is a separately rounded op: never contract a*b+c
+               "-ffp-contract=off", "-fno-fast-math"]
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def hip_sources():
+    return [os.path.join(CSRC, s) for s in HIP_SOURCES if os.path.exists(os.path.join(CSRC, s))]
+
+
+def build_hip(force: bool = False, verbose: bool = False) -> str:
+    srcs = hip_sources()
+    deps = srcs + [os.path.join(CSRC, "vbq_common.h"), os.path.join(INCLUDE, "vbq.h")]
+    if not force and not _newer(LIB, deps):
+        return LIB
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        raise RuntimeError("hipcc not found: cannot build libvbq_hip.so (ROCm toolchain required)")
+    os.makedirs(LIBDIR, exist_ok=True)
+    tmp = LIB + ".tmp"
+    cmd = [hipcc] + HIPCC_FLAGS + ["-I", INCLUDE, "-I", CSRC] + srcs + ["-o", tmp]
+    if verbose:
+        print(" ".join(cmd))
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
+    os.replace(tmp, LIB)
+    return LIB
+
+
+def build_oracle(force: bool = False) -> str:
+    """gcc build of oracle/vbq_oracle.c (test infrastructure, never loaded by vbq_amd)."""
+    odir = os.path.join(ROOT, "oracle")
+    r = subprocess.run(["make", "-C", odir] + (["-B"] if force else []), capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("oracle build failed:\n" + r.stdout + r.stderr)
+    return os.path.join(odir, "_build", "libvbq_oracle.so")
+
+
+if __name__ == "__main__":
+    print(build_hip(force="--force" in sys.argv, verbose=True))
+    if "--oracle" in sys.argv:
+        print(build_oracle(force="--force" in sys.argv))

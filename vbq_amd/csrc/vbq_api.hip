@@ -1,0 +1,46 @@
+// C-ABI plumbing: error string, ABI version, device queries.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "vbq_common.h"
+
+namespace vbq {
+namespace {
+thread_local char g_err[512] = "";
+}
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+}  // namespace vbq
+
+extern "C" int vbq_abi_version(void) { return VBQ_ABI_VERSION; }
+
+extern "C" const char *vbq_last_error(void) { return vbq::g_err; }
+
+extern "C" int vbq_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+extern "C" int vbq_device_name(int dev, char *buf, size_t buflen) {
+    if (!buf || buflen == 0) {
+        vbq::set_error("vbq_device_name: empty buffer");
+        return VBQ_ERR_INVALID_ARGUMENT;
+    }
+    hipDeviceProp_t p;
+    hipError_t e = hipGetDeviceProperties(&p, dev);
+    if (e != hipSuccess) {
+        vbq::set_error("vbq_device_name(%d): %s", dev, hipGetErrorString(e));
+        return VBQ_ERR_INVALID_ARGUMENT;
+    }
+    snprintf(buf, buflen, "%s (%s, %d CUs)", p.name, p.gcnArchName, p.multiProcessorCount);
+    return VBQ_OK;
+}

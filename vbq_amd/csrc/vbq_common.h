@@ -1,0 +1,45 @@
+// Shared device/host helpers for the VBQ HIP kernels (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "vbq.h"
+
+namespace vbq {
+
+void set_error(const char *fmt, ...);
+
+#define VBQ_REQUIRE(cond, code, ...)            \
+    do {                                        \
+        if (!(cond)) {                          \
+            ::vbq::set_error(__VA_ARGS__);      \
+            return (code);                      \
+        }                                       \
+    } while (0)
+
+#define VBQ_CHECK_LAUNCH(what)                                                        \
+    do {                                                                              \
+        hipError_t e__ = hipGetLastError();                                           \
+        if (e__ != hipSuccess) {                                                      \
+            ::vbq::set_error("%s: %s", (what), hipGetErrorString(e__));               \
+            return VBQ_ERR_LAUNCH;                                                    \
+        }                                                                             \
+    } while (0)
+
+constexpr int kWave = 64;
+constexpr int kTileChannels = 16;   // channel tables resident in LDS per workgroup (tiled kernel)
+constexpr int kMaxLambdaChunk = 32; // lambdas handled per launch (penalty table staged in LDS)
+
+__host__ __device__ constexpr int table_size(int N) { return (2 << N) - 1; }
+
+// Exactly-rounded f32 pieces of utils.py:319-320:  -0.5 * ((P - mu) / sigma) ** 2
+// (four separately rounded operations; the file is also built with -ffp-contract=off).
+__device__ __forceinline__ float neg_half_sq_err(float P, float mu, float sigma) {
+    float d = __fsub_rn(P, mu);
+    float t = __fdiv_rn(d, sigma);
+    float q = __fmul_rn(t, t);
+    return __fmul_rn(-0.5f, q);
+}
+
+}  // namespace vbq

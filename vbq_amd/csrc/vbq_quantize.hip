@@ -1,0 +1,435 @@
+// K1: the per-element rate-distortion solve of Variational Bayesian Quantization,
+// all lambdas in one pass over (mu, sigma).   gfx950 / CDNA4 only.
+//
+// Replaces (reference file:line): quantizer.py:65-80 (interval search), :156-188
+// (candidate assembly), utils.py:307-321 (distortion), utils.py:363-423 (per-lambda
+// argmax), quantizer.py:135,223 (index lookup).
+//
+// Data layout
+//   code-point table, level-major, in LDS: slot (n,i) at 2^n-1+i.  The descent
+//   G_n = 2 G_{n-1} + [p_n[G_{n-1}] < z] visits one point per bit level and that point
+//   is already the left or right neighbour of z on level n; the other neighbour is the
+//   adjacent slot.  21 LDS reads per element (N = 10) instead of 11 searches x 10 steps.
+//   Level-major (not sorted) order is what keeps those reads spread over the LDS banks:
+//   in sorted order every point of levels 0..5 lives on one bank.
+//   G_N is the lower bound of z in the merged sorted table, so every candidate's rank
+//   index is integer arithmetic on (G_N, level, side).
+// Arithmetic
+//   VBQ_MODE_F32: four separately rounded f32 ops per candidate, IEEE division,
+//   score = fl(s - fl(lambda*len)); candidates scanned in the reference order
+//   [L_0..L_N, R_1..R_N] with a strict '>' so the first maximum wins, as np/tf argmax do.
+#include "vbq_common.h"
+
+namespace vbq {
+namespace {
+
+template <int N>
+struct Elem {
+    float a[N + 1];   // distortion score of the left  neighbour on level n
+    float b[N + 1];   // distortion score of the right neighbour on level n   (b[0] == a[0])
+    uint32_t G;       // # table entries < z  (0..T)
+};
+
+// One descent through the level-major table `tb` (LDS).  Semantics of
+// quantizer.py:65-80 incl. the edge padding of the search grids (:54-57): below the
+// first / above the last point of a level both endpoints collapse onto it, except on the
+// deepest level where the grid has no padding and the left endpoint stays one slot back.
+template <int N>
+__device__ __forceinline__ void search_and_score(const float *tb, float z, float sg, Elem<N> &e) {
+    uint32_t g = 0;
+#pragma unroll
+    for (int n = 0; n <= N; ++n) {
+        const int off = (1 << n) - 1;
+        const int m = 1 << n;
+        const uint32_t j = g;
+        const float pj = tb[off + j];
+        const bool below = pj < z;                       // visited point is a LEFT neighbour
+        if (n == 0) {
+            const float s0 = neg_half_sq_err(pj, z, sg);
+            e.a[0] = s0;
+            e.b[0] = s0;
+        } else {
+            int jo = below ? (int)j + 1 : (int)j - 1;
+            jo = jo < 0 ? 0 : (jo > m - 1 ? m - 1 : jo);
+            bool swap = false;
+            if (n == N) {                                // no edge padding on the deepest level
+                if (below && j == (uint32_t)(m - 1)) { jo = m - 2; swap = true; }
+            }
+            const float po = tb[off + jo];
+            const float sj = neg_half_sq_err(pj, z, sg);
+            const float so = neg_half_sq_err(po, z, sg);
+            const bool j_is_left = below && !swap;
+            e.a[n] = j_is_left ? sj : so;
+            e.b[n] = j_is_left ? so : sj;
+        }
+        g = 2 * g + (below ? 1u : 0u);
+    }
+    e.G = g;
+}
+
+// Winner j in [0, 2N] (reference candidate order) -> level, slot within the level.
+template <int N>
+__device__ __forceinline__ void winner_slot(uint32_t G, int bj, int &lvl, uint32_t &pos) {
+    const int n = bj <= N ? bj : bj - N;
+    const bool right = bj > N;
+    const uint32_t Gn = G >> (N - n);
+    const uint32_t g = (Gn + 1) >> 1;                    // # level-n points < z
+    const uint32_t m = 1u << n;
+    uint32_t r = g < m - 1 ? g : m - 1;
+    uint32_t l = g > 0 ? g - 1 : 0;
+    if (n == N && N > 0 && g == m) l = m - 2;
+    lvl = n;
+    pos = right ? r : l;
+}
+
+template <int N>
+__device__ __forceinline__ int argmax_scan(const Elem<N> &e, const float (&p)[N + 1]) {
+    float best = __fsub_rn(e.a[0], p[0]);
+    int bj = 0;
+#pragma unroll
+    for (int n = 1; n <= N; ++n) {
+        const float sc = __fsub_rn(e.a[n], p[n]);
+        const bool up = sc > best;
+        best = up ? sc : best;
+        bj = up ? n : bj;
+    }
+#pragma unroll
+    for (int n = 1; n <= N; ++n) {
+        const float sc = __fsub_rn(e.b[n], p[n]);
+        const bool up = sc > best;
+        best = up ? sc : best;
+        bj = up ? N + n : bj;
+    }
+    return bj;
+}
+
+// f64-score variant (VBQ_MODE_F64_SCORE): score = fl64(f64(s) - fl64(lambda*len)).
+template <int N>
+__device__ __forceinline__ int argmax_scan_f64(const Elem<N> &e, const double (&p)[N + 1]) {
+    double best = __dsub_rn((double)e.a[0], p[0]);
+    int bj = 0;
+#pragma unroll
+    for (int n = 1; n <= N; ++n) {
+        const double sc = __dsub_rn((double)e.a[n], p[n]);
+        const bool up = sc > best;
+        best = up ? sc : best;
+        bj = up ? n : bj;
+    }
+#pragma unroll
+    for (int n = 1; n <= N; ++n) {
+        const double sc = __dsub_rn((double)e.b[n], p[n]);
+        const bool up = sc > best;
+        best = up ? sc : best;
+        bj = up ? N + n : bj;
+    }
+    return bj;
+}
+
+// ------------------------------------------------------------------------------------
+// penalty table: pen[l][c][n] = fl32(lambda_l) * len[l][c][n]   (len = n when raw)
+// f64 variant:   pen[l][c][n] = fl64(lambda_l * len)            (raw integer lengths only)
+// ------------------------------------------------------------------------------------
+struct LambdaChunk {
+    double lam[kMaxLambdaChunk];
+};
+
+template <typename T>
+__global__ void k_prepare_penalties(LambdaChunk lc, int L, int C, int N1, const float *__restrict__ level_len,
+                                    T *__restrict__ pen) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int total = L * C * N1;
+    if (i >= total) return;
+    const int n = i % N1;
+    const int l = i / (N1 * C);
+    if (sizeof(T) == 4) {
+        const float lam = (float)lc.lam[l];
+        const float len = level_len ? level_len[i] : (float)n;
+        pen[i] = (T)__fmul_rn(lam, len);
+    } else {
+        const double len = level_len ? (double)level_len[i] : (double)n;
+        pen[i] = (T)__dmul_rn(lc.lam[l], len);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// FLAT kernel: every element a workgroup touches uses the same table (one channel per
+// blockIdx.y; C == 1 or channel-major layout).  Penalties are wave-uniform -> scalar loads.
+// Each thread owns 4 consecutive elements: one 16-B load of mu and of sigma, one 8-B
+// store of 4 indices per lambda.
+// ------------------------------------------------------------------------------------
+template <int N, typename PenT>
+__global__ void __launch_bounds__(256)
+k_quant_flat(const float *__restrict__ mu, const float *__restrict__ sg, long n_per_ch, int C,
+             const float *__restrict__ table, const PenT *__restrict__ pen, const float *__restrict__ len,
+             int L, uint16_t *__restrict__ out_idx, float *__restrict__ out_zhat,
+             float *__restrict__ out_bits, long E, int vec_ok) {
+    constexpr int T = table_size(N);
+    constexpr int N1 = N + 1;
+    __shared__ float tb[T + 1];
+    const int c = blockIdx.y;
+    for (int i = threadIdx.x; i < T; i += blockDim.x) tb[i] = table[(long)c * T + i];
+    __syncthreads();
+
+    const long base = (long)c * n_per_ch;
+    const long nquads = (n_per_ch + 3) >> 2;
+    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < nquads; q += (long)gridDim.x * blockDim.x) {
+        const long i0 = q * 4;
+        const bool full = vec_ok && (i0 + 4 <= n_per_ch);
+        float m4[4], s4[4];
+        if (full) {
+            const float4 mv = *reinterpret_cast<const float4 *>(mu + base + i0);
+            const float4 sv = *reinterpret_cast<const float4 *>(sg + base + i0);
+            m4[0] = mv.x; m4[1] = mv.y; m4[2] = mv.z; m4[3] = mv.w;
+            s4[0] = sv.x; s4[1] = sv.y; s4[2] = sv.z; s4[3] = sv.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const bool ok = i0 + k < n_per_ch;
+                m4[k] = ok ? mu[base + i0 + k] : 0.0f;
+                s4[k] = ok ? sg[base + i0 + k] : 1.0f;
+            }
+        }
+        Elem<N> el[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) search_and_score<N>(tb, m4[k], s4[k], el[k]);
+
+        for (int l = 0; l < L; ++l) {
+            const PenT *pp = pen + ((long)l * C + c) * N1;
+            PenT p[N1];
+#pragma unroll
+            for (int n = 0; n < N1; ++n) p[n] = pp[n];
+            uint32_t idx[4];
+            float zh[4], bt[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                int bj;
+                if constexpr (sizeof(PenT) == 4) bj = argmax_scan<N>(el[k], p);
+                else bj = argmax_scan_f64<N>(el[k], p);
+                int lvl; uint32_t pos;
+                winner_slot<N>(el[k].G, bj, lvl, pos);
+                idx[k] = ((2 * pos + 1) << (N - lvl)) - 1;
+                if (out_zhat) zh[k] = tb[(1 << lvl) - 1 + pos];
+                if (out_bits) bt[k] = len ? len[((long)l * C + c) * N1 + lvl] : (float)lvl;
+            }
+            const long o = (long)l * E + base + i0;
+            if (full) {
+                uint2 pk;
+                pk.x = idx[0] | (idx[1] << 16);
+                pk.y = idx[2] | (idx[3] << 16);
+                *reinterpret_cast<uint2 *>(out_idx + o) = pk;
+                if (out_zhat) *reinterpret_cast<float4 *>(out_zhat + o) = make_float4(zh[0], zh[1], zh[2], zh[3]);
+                if (out_bits) *reinterpret_cast<float4 *>(out_bits + o) = make_float4(bt[0], bt[1], bt[2], bt[3]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (i0 + k < n_per_ch) {
+                        out_idx[o + k] = (uint16_t)idx[k];
+                        if (out_zhat) out_zhat[o + k] = zh[k];
+                        if (out_bits) out_bits[o + k] = bt[k];
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// TILED kernel: channel-last [rows][C] input with C > 1.  A workgroup keeps the tables of
+// 16 consecutive channels in LDS (16 x 8 KB, stride T+2 words so that the same slot of
+// different channels falls on different banks) plus this launch's penalty table for those
+// channels, and walks down the rows.  Lane = (channel lane, row slot): a wave covers 4 rows
+// x 16 channels, i.e. four 64-B input segments per load.  Each thread keeps kTiledNE rows of
+// its channel in flight (independent descents hide the LDS latency); its 11 penalties per
+// lambda are shared by those elements.
+// ------------------------------------------------------------------------------------
+constexpr int kTiledThreads = 1024;
+constexpr int kTiledNE = 2;                                         // rows in flight per thread
+constexpr int kRowsPerIter = (kTiledThreads / kTileChannels) * kTiledNE;
+
+template <int N, typename PenT>
+__global__ void __launch_bounds__(kTiledThreads)
+k_quant_tiled(const float *__restrict__ mu, const float *__restrict__ sg, long n_rows, int C,
+              const float *__restrict__ table, const PenT *__restrict__ pen, const float *__restrict__ len,
+              int L, uint16_t *__restrict__ out_idx, float *__restrict__ out_zhat,
+              float *__restrict__ out_bits, long E) {
+    constexpr int T = table_size(N);
+    constexpr int TS = T + 2;        // odd word stride: channel lane k is rotated by k banks
+    constexpr int N1 = N + 1;
+    constexpr int PS = (N1 + 3) & ~3;   // penalty row padded to a multiple of 4 entries
+    extern __shared__ __align__(16) unsigned char smem[];
+    constexpr bool kPenInLds = sizeof(PenT) == 4;   // f64 penalty rows do not fit next to 16 tables
+    float *tb = reinterpret_cast<float *>(smem);
+    PenT *pl = reinterpret_cast<PenT *>(smem + sizeof(float) * kTileChannels * TS + 16);
+
+    const int c0 = blockIdx.y * kTileChannels;
+    const int ncg = min(kTileChannels, C - c0);
+    for (int i = threadIdx.x; i < ncg * T; i += blockDim.x) {
+        const int ch = i / T, s = i - ch * T;
+        tb[ch * TS + s] = table[(long)(c0 + ch) * T + s];
+    }
+    if constexpr (kPenInLds) {
+        for (int i = threadIdx.x; i < L * ncg * N1; i += blockDim.x) {
+            const int n = i % N1;
+            const int ch = (i / N1) % ncg;
+            const int l = i / (N1 * ncg);
+            pl[(l * kTileChannels + ch) * PS + n] = pen[((long)l * C + c0 + ch) * N1 + n];
+        }
+    }
+    __syncthreads();
+
+    const int cl = threadIdx.x & (kTileChannels - 1);
+    const int slot = threadIdx.x >> 4;                     // 0..63
+    if (cl >= ncg) return;
+    const float *mytb = tb + cl * TS;
+    const int c = c0 + cl;
+
+    for (long rb = (long)blockIdx.x * kRowsPerIter; rb < n_rows; rb += (long)gridDim.x * kRowsPerIter) {
+        Elem<N> el[kTiledNE];
+        long row[kTiledNE];
+#pragma unroll
+        for (int k = 0; k < kTiledNE; ++k) {
+            row[k] = rb + k * 64 + slot;
+            const bool ok = row[k] < n_rows;
+            const float m = ok ? mu[row[k] * C + c] : 0.0f;
+            const float s = ok ? sg[row[k] * C + c] : 1.0f;
+            search_and_score<N>(mytb, m, s, el[k]);
+        }
+        for (int l = 0; l < L; ++l) {
+            PenT p[N1];
+            const PenT *pp = kPenInLds ? pl + (l * kTileChannels + cl) * PS : pen + ((long)l * C + c) * N1;
+#pragma unroll
+            for (int n = 0; n < N1; ++n) p[n] = pp[n];
+#pragma unroll
+            for (int k = 0; k < kTiledNE; ++k) {
+                int bj;
+                if constexpr (sizeof(PenT) == 4) bj = argmax_scan<N>(el[k], p);
+                else bj = argmax_scan_f64<N>(el[k], p);
+                int lvl; uint32_t pos;
+                winner_slot<N>(el[k].G, bj, lvl, pos);
+                if (row[k] < n_rows) {
+                    const long o = (long)l * E + row[k] * C + c;
+                    out_idx[o] = (uint16_t)(((2 * pos + 1) << (N - lvl)) - 1);
+                    if (out_zhat) out_zhat[o] = mytb[(1 << lvl) - 1 + pos];
+                    if (out_bits) out_bits[o] = len ? len[((long)l * C + c) * N1 + lvl] : (float)lvl;
+                }
+            }
+        }
+    }
+}
+
+template <int N, typename PenT>
+int launch_quantize(const float *mu, const float *sg, int64_t n_rows, int32_t n_ch, int32_t layout,
+                    const float *table, const float *level_len, const double *h_lambdas, int32_t L,
+                    uint16_t *out_idx, float *out_zhat, float *out_bits, void *ws, hipStream_t st) {
+    constexpr int N1 = N + 1;
+    const int64_t E = n_rows * (int64_t)n_ch;
+    PenT *pen = reinterpret_cast<PenT *>(ws);
+    const bool flat = (n_ch == 1) || (layout == VBQ_LAYOUT_CB);
+
+    for (int l0 = 0; l0 < L; l0 += kMaxLambdaChunk) {
+        const int Lc = (L - l0 < kMaxLambdaChunk) ? (L - l0) : kMaxLambdaChunk;
+        LambdaChunk lc;
+        for (int i = 0; i < kMaxLambdaChunk; ++i) lc.lam[i] = i < Lc ? h_lambdas[l0 + i] : 0.0;
+        const int total = Lc * n_ch * N1;
+        const float *len_c = level_len ? level_len + (int64_t)l0 * n_ch * N1 : nullptr;
+        hipLaunchKernelGGL((k_prepare_penalties<PenT>), dim3((total + 255) / 256), dim3(256), 0, st, lc, Lc,
+                           (int)n_ch, N1, len_c, pen);
+        VBQ_CHECK_LAUNCH("prepare_penalties");
+
+        uint16_t *oi = out_idx + (int64_t)l0 * E;
+        float *oz = out_zhat ? out_zhat + (int64_t)l0 * E : nullptr;
+        float *ob = out_bits ? out_bits + (int64_t)l0 * E : nullptr;
+        if (flat) {
+            const int64_t n_per_ch = (n_ch == 1) ? E : n_rows;
+            const int vec_ok = ((n_per_ch % 4 == 0) || n_ch == 1) &&
+                               ((reinterpret_cast<uintptr_t>(mu) | reinterpret_cast<uintptr_t>(sg)) % 16 == 0) &&
+                               (reinterpret_cast<uintptr_t>(oi) % 8 == 0) && (E % 4 == 0 || L == 1) &&
+                               (!oz || reinterpret_cast<uintptr_t>(oz) % 16 == 0) &&
+                               (!ob || reinterpret_cast<uintptr_t>(ob) % 16 == 0);
+            const int64_t nquads = (n_per_ch + 3) / 4;
+            int64_t gx = (nquads + 255) / 256;
+            const int64_t cap = (int64_t)256 * 8 / (n_ch < 8 ? n_ch : 8) + 1;   // ~8 resident workgroups per CU in total
+            if (gx > cap) gx = cap;
+            if (gx < 1) gx = 1;
+            hipLaunchKernelGGL((k_quant_flat<N, PenT>), dim3((unsigned)gx, (unsigned)n_ch), dim3(256), 0, st, mu, sg,
+                               (long)n_per_ch, (int)n_ch, table, pen, len_c, Lc, oi, oz, ob, (long)E, vec_ok);
+            VBQ_CHECK_LAUNCH("quant_flat");
+        } else {
+            constexpr int T = table_size(N);
+            constexpr int PS = (N1 + 3) & ~3;
+            const size_t lds = sizeof(float) * kTileChannels * (T + 2) + 16 +
+                               (sizeof(PenT) == 4 ? sizeof(PenT) * (size_t)kMaxLambdaChunk * kTileChannels * PS : 0);
+            static bool attr_set = false;
+            if (!attr_set) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_quant_tiled<N, PenT>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e != hipSuccess) {
+                    set_error("hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
+                    return VBQ_ERR_LAUNCH;
+                }
+                attr_set = true;
+            }
+            const int groups = (n_ch + kTileChannels - 1) / kTileChannels;
+            int64_t iters = (n_rows + kRowsPerIter - 1) / kRowsPerIter;
+            int64_t gx = (256 + groups - 1) / groups;          // one workgroup per CU
+            if (gx > iters) gx = iters;
+            if (gx < 1) gx = 1;
+            hipLaunchKernelGGL((k_quant_tiled<N, PenT>), dim3((unsigned)gx, (unsigned)groups), dim3(kTiledThreads),
+                               lds, st, mu, sg, (long)n_rows, (int)n_ch, table, pen, len_c, Lc, oi, oz, ob, (long)E);
+            VBQ_CHECK_LAUNCH("quant_tiled");
+        }
+    }
+    return VBQ_OK;
+}
+
+}  // namespace
+}  // namespace vbq
+
+extern "C" size_t vbq_quantize_workspace_bytes(int32_t n_ch, int32_t n_lambda, int32_t N) {
+    if (n_ch <= 0 || n_lambda <= 0 || N < 0) return 0;
+    const int Lc = n_lambda < vbq::kMaxLambdaChunk ? n_lambda : vbq::kMaxLambdaChunk;
+    return (size_t)Lc * (size_t)n_ch * (size_t)(N + 1) * sizeof(double) + 256;
+}
+
+extern "C" int vbq_quantize_f32(const float *d_mu, const float *d_sigma, int64_t n_rows, int32_t n_ch,
+                                int32_t layout, const float *d_table_lm, const float *d_level_len,
+                                const double *h_lambdas, int32_t n_lambda, int32_t N, int32_t mode,
+                                uint16_t *d_out_idx, float *d_out_zhat, float *d_out_bits, void *d_workspace,
+                                size_t workspace_bytes, void *stream) {
+    using namespace vbq;
+    VBQ_REQUIRE(n_rows >= 0 && n_ch >= 1 && n_lambda >= 1, VBQ_ERR_INVALID_ARGUMENT,
+                "vbq_quantize_f32: bad sizes n_rows=%lld n_ch=%d n_lambda=%d", (long long)n_rows, n_ch, n_lambda);
+    VBQ_REQUIRE(n_rows == 0 || (d_mu && d_sigma && d_table_lm && h_lambdas && d_out_idx), VBQ_ERR_INVALID_ARGUMENT,
+                "vbq_quantize_f32: null pointer argument");
+    VBQ_REQUIRE(layout == VBQ_LAYOUT_BC || layout == VBQ_LAYOUT_CB, VBQ_ERR_INVALID_ARGUMENT,
+                "vbq_quantize_f32: unknown layout %d", layout);
+    VBQ_REQUIRE(mode == VBQ_MODE_F32 || mode == VBQ_MODE_F64_SCORE, VBQ_ERR_INVALID_ARGUMENT,
+                "vbq_quantize_f32: unknown mode %d", mode);
+    VBQ_REQUIRE(!(mode == VBQ_MODE_F64_SCORE && d_level_len), VBQ_ERR_UNSUPPORTED,
+                "vbq_quantize_f32: VBQ_MODE_F64_SCORE supports raw integer lengths only");
+    VBQ_REQUIRE(n_ch <= 65535, VBQ_ERR_UNSUPPORTED, "vbq_quantize_f32: n_ch=%d exceeds 65535", n_ch);
+    const size_t need = vbq_quantize_workspace_bytes(n_ch, n_lambda, N);
+    VBQ_REQUIRE(d_workspace && workspace_bytes >= need, VBQ_ERR_WORKSPACE,
+                "vbq_quantize_f32: workspace of %zu bytes given, %zu needed", workspace_bytes, need);
+    if (n_rows == 0) return VBQ_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#define VBQ_DISPATCH_N(NN)                                                                                         \
+    case NN:                                                                                                       \
+        return mode == VBQ_MODE_F32                                                                                \
+                   ? launch_quantize<NN, float>(d_mu, d_sigma, n_rows, n_ch, layout, d_table_lm, d_level_len,      \
+                                                h_lambdas, n_lambda, d_out_idx, d_out_zhat, d_out_bits,            \
+                                                d_workspace, st)                                                   \
+                   : launch_quantize<NN, double>(d_mu, d_sigma, n_rows, n_ch, layout, d_table_lm, d_level_len,     \
+                                                 h_lambdas, n_lambda, d_out_idx, d_out_zhat, d_out_bits,           \
+                                                 d_workspace, st);
+    switch (N) {
+        VBQ_DISPATCH_N(10)
+        VBQ_DISPATCH_N(8)
+        VBQ_DISPATCH_N(6)
+        VBQ_DISPATCH_N(4)
+        default:
+            set_error("vbq_quantize_f32: max_bits_per_coord N=%d not built (have 4, 6, 8, 10)", N);
+            return VBQ_ERR_UNSUPPORTED;
+    }
+#undef VBQ_DISPATCH_N
+}

@@ -1,0 +1,210 @@
+"""Torch-tensor front end of the C-ABI (include/vbq.h).  PyTorch supplies device memory and
+the current HIP stream; all arithmetic happens in libvbq_hip.so.  Every function raises
+(VBQError / ValueError) instead of falling back to anything slower."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import LAYOUT_BC, LAYOUT_CB, MODE_F32, MODE_F64_SCORE, VBQError, check
+
+_LAYOUTS = {"bc": LAYOUT_BC, "cb": LAYOUT_CB, LAYOUT_BC: LAYOUT_BC, LAYOUT_CB: LAYOUT_CB}
+_MODES = {"f32": MODE_F32, "f64": MODE_F64_SCORE, MODE_F32: MODE_F32, MODE_F64_SCORE: MODE_F64_SCORE}
+
+
+def table_size(N: int) -> int:
+    return 2 ** (N + 1) - 1
+
+
+def _stream(t: torch.Tensor):
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _dev(t: torch.Tensor, dtype, name: str) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise ValueError(f"{name}: expected a torch tensor, got {type(t).__name__}")
+    if not t.is_cuda:
+        raise VBQError(f"{name}: tensor is on {t.device}; the VBQ kernels only run on a ROCm device "
+                       "(there is no CPU implementation in this package)")
+    if t.dtype != dtype:
+        raise ValueError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    return t.contiguous()
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _doubles(vals: Sequence[float]):
+    arr = (C.c_double * len(vals))(*[float(v) for v in vals])
+    return arr
+
+
+def _rows_channels(shape, layout):
+    if len(shape) == 1:
+        return shape[0], 1
+    if len(shape) != 2:
+        raise ValueError(f"expected a 1-D or 2-D tensor, got shape {tuple(shape)}")
+    return (shape[0], shape[1]) if layout == LAYOUT_BC else (shape[1], shape[0])
+
+
+def quantize(mu: torch.Tensor, sigma: torch.Tensor, table_lm: torch.Tensor, lambdas: Sequence[float], *,
+             N: int = 10, level_len: Optional[torch.Tensor] = None, layout="bc", mode="f32",
+             want_zhat: bool = False, want_bits: bool = False):
+    """K1 (vbq_quantize_f32).  mu, sigma: f32 [rows, C] (layout 'bc') / [C, rows] ('cb') / [n] (C = 1).
+    table_lm: f32 [C, T] level-major.  level_len: optional f32 [L, C, N+1].
+    Returns idx u16 [L, *mu.shape] and, when asked, zhat / bits f32 of the same shape."""
+    layout = _LAYOUTS[layout]
+    mode = _MODES[mode]
+    mu = _dev(mu, torch.float32, "mu")
+    sigma = _dev(sigma, torch.float32, "sigma")
+    if mu.shape != sigma.shape:
+        raise ValueError(f"mu {tuple(mu.shape)} and sigma {tuple(sigma.shape)} differ in shape")
+    rows, Cc = _rows_channels(mu.shape, layout)
+    T = table_size(N)
+    table_lm = _dev(table_lm, torch.float32, "table_lm")
+    if table_lm.numel() != Cc * T:
+        raise ValueError(f"table_lm has {table_lm.numel()} entries, expected C*T = {Cc}*{T}")
+    L = len(lambdas)
+    if L < 1:
+        raise ValueError("need at least one lambda")
+    if level_len is not None:
+        level_len = _dev(level_len, torch.float32, "level_len")
+        if tuple(level_len.shape) != (L, Cc, N + 1):
+            raise ValueError(f"level_len shape {tuple(level_len.shape)} != {(L, Cc, N + 1)}")
+    h = _lib.lib()
+    idx = torch.empty((L,) + tuple(mu.shape), dtype=torch.uint16, device=mu.device)
+    zhat = torch.empty((L,) + tuple(mu.shape), dtype=torch.float32, device=mu.device) if want_zhat else None
+    bits = torch.empty((L,) + tuple(mu.shape), dtype=torch.float32, device=mu.device) if want_bits else None
+    wsb = h.vbq_quantize_workspace_bytes(Cc, L, N)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=mu.device)
+    check(h.vbq_quantize_f32(_ptr(mu), _ptr(sigma), rows, Cc, layout, _ptr(table_lm), _ptr(level_len),
+                             _doubles(lambdas), L, N, mode, _ptr(idx), _ptr(zhat), _ptr(bits), _ptr(ws), wsb,
+                             _stream(mu)), "vbq_quantize_f32")
+    out = (idx,)
+    if want_zhat:
+        out += (zhat,)
+    if want_bits:
+        out += (bits,)
+    return out if len(out) > 1 else idx
+
+
+def quantize_notebook(means: torch.Tensor, stds: torch.Tensor, codebook_lm: torch.Tensor, betas: Sequence[float], *,
+                      N: int = 10, want_values: bool = True):
+    """K1n (vbq_quantize_notebook_f64).  Returns (idx u16 [n_beta, *shape], values f32 or None)."""
+    means = _dev(means, torch.float32, "means")
+    stds = _dev(stds, torch.float32, "stds")
+    if means.shape != stds.shape:
+        raise ValueError("means and stds differ in shape")
+    codebook_lm = _dev(codebook_lm, torch.float64, "codebook_lm")
+    if codebook_lm.numel() != table_size(N):
+        raise ValueError(f"codebook has {codebook_lm.numel()} entries, expected {table_size(N)}")
+    nb = len(betas)
+    n = means.numel()
+    idx = torch.empty((nb,) + tuple(means.shape), dtype=torch.uint16, device=means.device)
+    val = torch.empty((nb,) + tuple(means.shape), dtype=torch.float32, device=means.device) if want_values else None
+    check(_lib.lib().vbq_quantize_notebook_f64(_ptr(means), _ptr(stds), n, _ptr(codebook_lm), _doubles(betas), nb, N,
+                                               _ptr(idx), _ptr(val), _stream(means)), "vbq_quantize_notebook_f64")
+    return idx, val
+
+
+def histogram(idx: torch.Tensor, n_ch: int, *, N: int = 10, layout="bc", out: Optional[torch.Tensor] = None):
+    """K2 (vbq_histogram_u16).  idx: u16 [L, rows, C] / [L, C, rows] / [L, n].  Returns int64 [L, C, T]
+    (added into `out` when given)."""
+    layout = _LAYOUTS[layout]
+    idx = _dev(idx, torch.uint16, "idx")
+    L = idx.shape[0]
+    E = idx[0].numel()
+    if E % n_ch:
+        raise ValueError(f"{E} indices per lambda is not a multiple of n_ch={n_ch}")
+    rows = E // n_ch
+    T = table_size(N)
+    if out is None:
+        out = torch.zeros((L, n_ch, T), dtype=torch.int64, device=idx.device)
+    else:
+        out = _dev(out, torch.int64, "out")
+        if tuple(out.shape) != (L, n_ch, T):
+            raise ValueError(f"out shape {tuple(out.shape)} != {(L, n_ch, T)}")
+    check(_lib.lib().vbq_histogram_u16(_ptr(idx), rows, n_ch, layout, L, N, _ptr(out), _stream(idx)),
+          "vbq_histogram_u16")
+    return out
+
+
+def moments(x: torch.Tensor, *, layout="bc", out: Optional[torch.Tensor] = None):
+    """K3 (vbq_moments_f32).  Returns f64 [C, 2] = (sum x, sum x^2) per channel."""
+    layout = _LAYOUTS[layout]
+    x = _dev(x, torch.float32, "x")
+    rows, Cc = _rows_channels(x.shape, layout)
+    if out is None:
+        out = torch.zeros((Cc, 2), dtype=torch.float64, device=x.device)
+    check(_lib.lib().vbq_moments_f32(_ptr(x), rows, Cc, layout, _ptr(out), _stream(x)), "vbq_moments_f32")
+    return out
+
+
+def gather(idx: torch.Tensor, tab: torch.Tensor, n_ch: int, *, N: int = 10, layout="bc"):
+    """vbq_gather_f32: out[l][e] = tab[(l,) c(e), idx[l][e]].  tab: f32 [C, T] or [L, C, T] indexed by RANK."""
+    layout = _LAYOUTS[layout]
+    idx = _dev(idx, torch.uint16, "idx")
+    tab = _dev(tab, torch.float32, "tab")
+    L = idx.shape[0]
+    E = idx[0].numel()
+    rows = E // n_ch
+    T = table_size(N)
+    per_lambda = tab.dim() == 3
+    if tuple(tab.shape) != ((L, n_ch, T) if per_lambda else (n_ch, T)):
+        raise ValueError(f"tab shape {tuple(tab.shape)} does not match (L={L}, C={n_ch}, T={T})")
+    out = torch.empty(idx.shape, dtype=torch.float32, device=idx.device)
+    check(_lib.lib().vbq_gather_f32(_ptr(idx), rows, n_ch, layout, L, N, _ptr(tab), int(per_lambda), _ptr(out),
+                                    _stream(idx)), "vbq_gather_f32")
+    return out
+
+
+def argmax_candidates(P: torch.Tensor, lens: torch.Tensor, mu: torch.Tensor, sigma: torch.Tensor,
+                      lambdas: Sequence[float], *, mode="f32", want_j=False):
+    """K1c (vbq_argmax_candidates_f32).  P: f32 [M, *shape]; lens: f32 [M, *shape] or [L, M, *shape]."""
+    mode = _MODES[mode]
+    P = _dev(P, torch.float32, "P")
+    lens = _dev(lens, torch.float32, "lens")
+    mu = _dev(mu, torch.float32, "mu")
+    sigma = _dev(sigma, torch.float32, "sigma")
+    M = P.shape[0]
+    L = len(lambdas)
+    if tuple(P.shape[1:]) != tuple(mu.shape) or mu.shape != sigma.shape:
+        raise ValueError("P must be [M, *mu.shape] and sigma must match mu")
+    per_lambda = lens.dim() == P.dim() + 1
+    if tuple(lens.shape) != (((L,) if per_lambda else ()) + tuple(P.shape)):
+        raise ValueError(f"lens shape {tuple(lens.shape)} incompatible with P {tuple(P.shape)} and L={L}")
+    n = mu.numel()
+    zhat = torch.empty((L,) + tuple(mu.shape), dtype=torch.float32, device=mu.device)
+    bits = torch.empty_like(zhat)
+    j = torch.empty((L,) + tuple(mu.shape), dtype=torch.uint8, device=mu.device) if want_j else None
+    check(_lib.lib().vbq_argmax_candidates_f32(_ptr(P), _ptr(lens), int(per_lambda), _ptr(mu), _ptr(sigma), n,
+                                               _doubles(lambdas), L, M, mode, _ptr(j), _ptr(zhat), _ptr(bits),
+                                               _stream(mu)), "vbq_argmax_candidates_f32")
+    return (zhat, bits, j) if want_j else (zhat, bits)
+
+
+def bmshj_cdf_pdf(params: torch.Tensor, x: torch.Tensor, *, cdf=True, pdf=True, logpdf=False):
+    """K4 (vbq_bmshj_cdf_pdf_f32).  params: f32 [C, 43] effective parameters; x: f32 [..., C]."""
+    params = _dev(params, torch.float32, "params")
+    x = _dev(x, torch.float32, "x")
+    Cc = params.shape[0]
+    if params.shape[1] != _lib.BMSHJ_PARAMS_PER_CHANNEL or x.shape[-1] != Cc:
+        raise ValueError(f"params must be [C, 43] and x [..., C]; got {tuple(params.shape)}, {tuple(x.shape)}")
+    rows = x.numel() // Cc
+    outs = [torch.empty_like(x) if f else None for f in (cdf, pdf, logpdf)]
+    check(_lib.lib().vbq_bmshj_cdf_pdf_f32(_ptr(params), _ptr(x), rows, Cc, _ptr(outs[0]), _ptr(outs[1]), _ptr(outs[2]),
+                                           _stream(x)), "vbq_bmshj_cdf_pdf_f32")
+    return tuple(outs)
+
+
+def bmshj_icdf_step(params, xi, left, right, mid, flags):
+    """K4 (vbq_bmshj_icdf_step_f32): one in-place bisection update; flags u32[2] must be preset to (0, 0x7f800000)."""
+    Cc = params.shape[0]
+    rows = xi.numel() // Cc
+    check(_lib.lib().vbq_bmshj_icdf_step_f32(_ptr(params), _ptr(xi), rows, Cc, _ptr(left), _ptr(right), _ptr(mid),
+                                             _ptr(flags), _stream(xi)), "vbq_bmshj_icdf_step_f32")
