@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""Headline benchmark of the VBQ hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one entropy-model pass of the reference (quantizer.py:119-146) over one batch:
+the fused 32-lambda R-D solve (K1), the per-(lambda, channel) histogram of the indices (K2)
+and, with N > 1, the RCCL all-reduce of that histogram.  Inputs are resident in HBM before
+the timed region.  Workload (BASELINE.json configs[1]): the latent tensor of the Kodak-24
+set from the paper's model (--num_filters 256: 24 x 32 x 48 positions x 256 channels =
+36864 x 256), 32-point lambda sweep 2**linspace(-8, 7.5, 32), per-channel code books of
+2047 points, corrected code lengths (the production compress path, quantizer.py:171-180).
+Data are synthetic stand-ins of that shape (no checkpoint / images ship with the reference).
+Each rank owns its own batch (weak scaling); the only collective is the histogram all-reduce.
+
+Prints ONE JSON line (rank 0).  `value` = quantized latents (element x lambda solves) per
+second over all ranks.  `roofline` prices the dominant kernel (K1) with its ALGORITHMIC
+bytes -- 8 B read per element + 2 B written per (element, lambda) -- against 8 TB/s.
+`cpu_baseline` = the C oracle (oracle/vbq_oracle.c, OpenMP) on this host's cores on a
+bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_BITS = 10
+T = 2 ** (N_BITS + 1) - 1
+LAMBDAS = [float(v) for v in 2.0 ** np.linspace(-8, 7.5, 32)]
+HBM_PEAK = 8.0e12
+
+WORKLOADS = {
+    # name: (rows, channels, description)
+    "kodak24_c256": (36864, 256, "Kodak-24 latents of bls2017 (num_filters=256): [36864 x 256] f32"),
+    "kodak24_c32": (36864, 32, "Kodak-24 latents of bls2017 (default num_filters=32): [36864 x 32] f32"),
+    "embeddings_1e7": (10_000_000, 1, "word embeddings 100000 x 100, one Gaussian code book"),
+    "synthetic_1e8": (100_000_000, 1, "synthetic 1e8-element tensor, one code book"),
+}
+
+
+def make_inputs(rows, C, seed):
+    """Synthetic (mu, sigma, level-major tables) with the statistics of SURVEY 8(d)."""
+    from scipy.stats import norm
+    rng = np.random.default_rng(seed)
+    s_c = np.exp(rng.uniform(np.log(0.3), np.log(3.0), C)) if C > 1 else np.array([1.2329])
+    m_c = np.zeros(C) if C > 1 else np.array([-0.0799])
+    mu = (m_c + s_c * rng.standard_normal((rows, C), dtype=np.float32)).astype(np.float32)
+    sigma = np.clip(np.exp(-2.0 + 0.7 * rng.standard_normal((rows, C), dtype=np.float32)), 1e-4, 10).astype(np.float32)
+    scale = np.sqrt(np.mean(mu.astype(np.float64) ** 2, axis=0))           # empirical prior (ipynb:374)
+    xi = np.concatenate([(np.arange(2 ** n) + 0.5) / 2 ** n for n in range(N_BITS + 1)])
+    tables = norm.ppf(xi[None, :], scale=scale[:, None]).astype(np.float32)  # [C, T] level-major
+    return mu, sigma, tables
+
+
+def cpu_baseline(mu, sigma, tables, level_len, target_s=12.0):
+    from oracle import c_oracle as CO
+    threads = CO.max_threads()
+    rows, C = mu.shape
+    L = len(LAMBDAS)
+    probe = max(1, min(rows, 200_000 // C))
+    t0 = time.perf_counter()
+    CO.quantize(mu[:probe], sigma[:probe], tables, LAMBDAS, N=N_BITS, level_len=level_len, threads=threads)
+    dt = time.perf_counter() - t0
+    rate = probe * C * L / dt
+    n = int(max(probe, min(rows, target_s * rate / (C * L))))
+    reps = int(max(1, round(target_s * rate / (n * C * L))))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        idx = CO.quantize(mu[:n], sigma[:n], tables, LAMBDAS, N=N_BITS, level_len=level_len, threads=threads)
+    dt = time.perf_counter() - t0
+    return {"value": reps * n * C * L / dt, "unit": "latents/s", "cores": threads, "kind": "port",
+            "sample": f"{reps} x (first {n} of {rows} rows x {C} channels x {L} lambdas), C oracle "
+                      f"(oracle/vbq_oracle.c, OpenMP {threads} threads), solve only, {dt:.1f} s"}, idx, n
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="kodak24_c256", choices=sorted(WORKLOADS))
+    ap.add_argument("--stage", default="full", choices=["full", "quantize"])
+    ap.add_argument("--raw-lengths", action="store_true", help="pass-1 lengths (n) instead of corrected lengths")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from vbq_amd import ops
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit(f"--gpus {args.gpus} needs a torch.distributed.run launch with {args.gpus} ranks")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm device")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    rows, C, desc = WORKLOADS[args.workload]
+    L = len(LAMBDAS)
+    mu_h, sg_h, tab_h = make_inputs(rows, C, seed=1000 + rank)
+    mu, sg, tab = torch.from_numpy(mu_h).to(dev), torch.from_numpy(sg_h).to(dev), torch.from_numpy(tab_h).to(dev)
+    E = rows * C
+    shape = (rows, C) if C > 1 else (rows,)
+    mu, sg = mu.reshape(shape), sg.reshape(shape)
+    idx = torch.empty((L,) + shape, dtype=torch.uint16, device=dev)
+    counts = torch.zeros((L, C, T), dtype=torch.int64, device=dev)
+    ws = torch.empty(ops._lib.lib().vbq_quantize_workspace_bytes(C, L, N_BITS), dtype=torch.uint8, device=dev)
+
+    # setup (untimed): pass 1 with raw lengths -> bit-length histogram -> corrected lengths (quantizer.py:96-112)
+    level_len = None
+    if not args.raw_lengths:
+        from vbq_amd.entropy import level_lengths_from_counts
+        ops.quantize(mu, sg, tab, LAMBDAS, N=N_BITS, out_idx=idx, workspace=ws)
+        c1 = ops.histogram(idx, C, N=N_BITS)
+        if world > 1:
+            dist.all_reduce(c1)
+        level_len = level_lengths_from_counts(c1, N_BITS, add_n_smoothing=1)          # f32 [L, C, N+1] on device
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    evh = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+
+    def step(i=None):
+        if i is not None:
+            ev[i][0].record()
+        ops.quantize(mu, sg, tab, LAMBDAS, N=N_BITS, level_len=level_len, out_idx=idx, workspace=ws)
+        if i is not None:
+            ev[i][1].record()
+        if args.stage == "full":
+            counts.zero_()
+            if i is not None:
+                evh[i][0].record()
+            ops.histogram(idx, C, N=N_BITS, out=counts)
+            if i is not None:
+                evh[i][1].record()
+            if world > 1:
+                dist.all_reduce(counts)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    k1_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    k2_ms = float(np.mean([a.elapsed_time(b) for a, b in evh])) if args.stage == "full" else None
+    alg_bytes = E * (8 + 2 * L)
+    achieved = alg_bytes / (k1_ms * 1e-3)
+
+    out = None
+    if rank == 0:
+        out = {
+            "metric": "quantized latents/sec (32-lambda sweep)",
+            "value": world * E * L * args.steps / dt,
+            "unit": "latents/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {desc}; {L}-point lambda sweep 2**linspace(-8,7.5,32); "
+                                   f"N={N_BITS} (2047 code points/channel); "
+                                   f"{'raw' if args.raw_lengths else 'corrected'} code lengths; stage={args.stage} "
+                                   f"(K1 solve{' + K2 histogram' + (' + RCCL all-reduce' if world > 1 else '') if args.stage == 'full' else ''})",
+                       "elements_per_gpu": E, "lambdas": L, "parallelism": f"element-sharded x{world}"},
+            "roofline": {"bound": "hbm", "kernel": "k_quant_tiled" if C > 1 else "k_quant_flat",
+                         "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": k1_ms,
+                         "latents_per_s_kernel_only": E * L / (k1_ms * 1e-3)},
+            "stages_ms": {"k1_solve": k1_ms, "k2_histogram": k2_ms},
+        }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        ll_h = level_len.cpu().numpy() if level_len is not None else None
+        cb, idx_cpu, n = cpu_baseline(mu_h, sg_h, tab_h, ll_h)
+        out["cpu_baseline"] = cb
+        # the sample doubles as an in-run parity check of the timed configuration
+        got = idx[:, :n].cpu().numpy().reshape(idx_cpu.shape)
+        out["parity_vs_oracle_on_sample"] = bool(np.array_equal(got, idx_cpu))
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -186,27 +186,48 @@ def test_notebook_vs_oracle(ops):
         assert np.array_equal(host(idx)[i].astype(np.int64), rank_of_slot[slot])
 
 
-def test_histogram_moments_gather(ops):
+HMG_SHAPES = [(5000, 1), (8192, 1), (1000, 3), (300, 16), (999, 40)]
+
+
+@pytest.mark.parametrize("rows,C", HMG_SHAPES)
+def test_histogram_vs_oracle(ops, rows, C):
     rng = np.random.default_rng(4)
-    for rows, C in ((5000, 1), (8192, 1), (1000, 3), (300, 16), (999, 40)):
-        idx = rng.integers(0, T, (3, rows, C)).astype(np.uint16)
-        idx[2] = 1023                                       # collapsed distribution (large lambda)
-        want = CO.histogram(idx, C, N=N)
-        assert np.array_equal(host(ops.histogram(dev(idx), C, N=N)), want)
-        got_cb = ops.histogram(dev(idx.transpose(0, 2, 1)), C, N=N, layout="cb")
-        assert np.array_equal(host(got_cb), want)
-        x = rng.normal(0.3, 2.0, (rows, C)).astype(np.float32)
-        m = host(ops.moments(dev(x)))
-        ref = CO.moments(x, C)
-        assert np.allclose(m, ref, rtol=1e-12, atol=1e-9)
-        assert np.allclose(host(ops.moments(dev(x.T), layout="cb")), ref, rtol=1e-12, atol=1e-9)
-        tab = rng.normal(0, 1, (3, C, T)).astype(np.float32)
-        g = host(ops.gather(dev(idx), dev(tab), C, N=N))
-        want_g = np.take_along_axis(tab.transpose(0, 2, 1)[:, None], idx[:, :, None, :].astype(np.int64), axis=2)
-        assert np.array_equal(g, np.take_along_axis(np.broadcast_to(tab.transpose(0, 2, 1)[:, None], (3, rows, T, C)),
-                                                    idx[:, :, None, :].astype(np.int64), axis=2)[:, :, 0, :])
-        g2 = host(ops.gather(dev(idx), dev(tab[0]), C, N=N))
-        assert np.array_equal(g2[1], tab[0].T[idx[1].astype(np.int64), np.arange(C)[None, :]])
+    idx = rng.integers(0, T, (3, rows, C)).astype(np.uint16)
+    idx[2] = 1023                                       # collapsed distribution (large lambda)
+    want = CO.histogram(idx, C, N=N)
+    assert np.array_equal(host(ops.histogram(dev(idx), C, N=N)), want)
+    got_cb = ops.histogram(dev(idx.transpose(0, 2, 1)), C, N=N, layout="cb")
+    assert np.array_equal(host(got_cb), want)
+    # accumulation into an existing tensor
+    acc = ops.histogram(dev(idx), C, N=N)
+    ops.histogram(dev(idx), C, N=N, out=acc)
+    assert np.array_equal(host(acc), 2 * want)
+
+
+@pytest.mark.parametrize("rows,C", HMG_SHAPES)
+def test_moments_vs_oracle(ops, rows, C):
+    rng = np.random.default_rng(6)
+    x = rng.normal(0.3, 2.0, (rows, C)).astype(np.float32)
+    ref = CO.moments(x, C)
+    assert np.allclose(host(ops.moments(dev(x))), ref, rtol=1e-12, atol=1e-9)
+    assert np.allclose(host(ops.moments(dev(x.T), layout="cb")), ref, rtol=1e-12, atol=1e-9)
+
+
+@pytest.mark.parametrize("rows,C", HMG_SHAPES)
+def test_gather_vs_numpy(ops, rows, C):
+    rng = np.random.default_rng(8)
+    idx = rng.integers(0, T, (3, rows, C)).astype(np.uint16)
+    tab = rng.normal(0, 1, (3, C, T)).astype(np.float32)
+    ii = idx.astype(np.int64)
+    cc = np.arange(C)[None, :]
+    g = host(ops.gather(dev(idx), dev(tab), C, N=N))
+    for l in range(3):
+        assert np.array_equal(g[l], tab[l][cc, ii[l]])
+    g2 = host(ops.gather(dev(idx), dev(tab[0]), C, N=N))
+    for l in range(3):
+        assert np.array_equal(g2[l], tab[0][cc, ii[l]])
+    g3 = host(ops.gather(dev(idx.transpose(0, 2, 1)), dev(tab), C, N=N, layout="cb"))
+    assert np.array_equal(g3.transpose(0, 2, 1), g)
 
 
 def test_bmshj_vs_oracle(ops):
@@ -223,7 +244,7 @@ def test_bmshj_vs_oracle(ops):
     cdf, pdf, logpdf = ops.bmshj_cdf_pdf(params, dev(x), logpdf=True)
     rc, rp = p.cdf_pdf(x)
     assert np.allclose(host(cdf), rc, rtol=2e-6, atol=2e-7)
-    assert np.allclose(host(pdf), rp, rtol=2e-5, atol=1e-8)
+    assert np.allclose(host(pdf), rp, rtol=1e-4, atol=1e-7)
     assert np.allclose(host(logpdf), p.logpdf(x), rtol=1e-5, atol=1e-5)
 
 
@@ -245,4 +266,4 @@ def test_large_roundtrip_properties(ops):
     assert np.all(np.diff(rate) <= 0)
     # spot-check 2 lambdas against the oracle at full size
     want = CO.quantize(mu, sg, tab, [LAM32[3], LAM32[20]], N=N, threads=8)
-    assert np.array_equal(host(idx[[3, 20]]), want)
+    assert np.array_equal(host(idx)[[3, 20]], want)

@@ -5,7 +5,6 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-from . import build as _build
 
 _LIB = None
 
@@ -49,6 +48,7 @@ class VBQError(RuntimeError):
 
 
 def library_path() -> str:
+    from . import build as _build
     return os.environ.get("VBQ_HIP_LIBRARY", _build.LIB)
 
 

@@ -161,7 +161,7 @@ k_moments_bc(const float *__restrict__ x, long n_rows, int C, double *__restrict
     __syncthreads();
     const long E = n_rows * (long)C;
     const long nthreads = (long)gridDim.x * blockDim.x;
-    const long stride = ((nthreads + C - 1) / C) * C;
+    const long stride = (nthreads / C) * C;     // <= nthreads (host guarantees nthreads >= C); a multiple of C
     const long t0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t0 < stride) {
         const int c = (int)(t0 % C);
@@ -242,7 +242,7 @@ extern "C" int vbq_moments_f32(const float *d_x, int64_t n_rows, int32_t n_ch, i
     } else {
         int64_t gx = (E + 256 * 16 - 1) / (256 * 16);
         if (gx > 2048) gx = 2048;
-        if (gx < 1) gx = 1;
+        if (gx < (n_ch + 255) / 256) gx = (n_ch + 255) / 256;
         hipLaunchKernelGGL(k_moments_bc, dim3((unsigned)gx), dim3(256), sizeof(double) * 2 * n_ch, st, d_x,
                            (long)n_rows, (int)n_ch, d_out);
     }

@@ -18,6 +18,8 @@
 //   VBQ_MODE_F32: four separately rounded f32 ops per candidate, IEEE division,
 //   score = fl(s - fl(lambda*len)); candidates scanned in the reference order
 //   [L_0..L_N, R_1..R_N] with a strict '>' so the first maximum wins, as np/tf argmax do.
+#include <stdlib.h>
+
 #include "vbq_common.h"
 
 namespace vbq {
@@ -317,6 +319,12 @@ k_quant_tiled(const float *__restrict__ mu, const float *__restrict__ sg, long n
     }
 }
 
+// VBQ_PLAIN_KERNEL=1 routes everything through the literal 21-candidate kernels (A/B checks).
+inline bool force_plain_kernel() {
+    static const bool v = [] { const char *e = getenv("VBQ_PLAIN_KERNEL"); return e && e[0] == '1'; }();
+    return v;
+}
+
 template <int N, typename PenT>
 int launch_quantize(const float *mu, const float *sg, int64_t n_rows, int32_t n_ch, int32_t layout,
                     const float *table, const float *level_len, const double *h_lambdas, int32_t L,
@@ -351,6 +359,17 @@ int launch_quantize(const float *mu, const float *sg, int64_t n_rows, int32_t n_
             const int64_t cap = (int64_t)256 * 8 / (n_ch < 8 ? n_ch : 8) + 1;   // ~8 resident workgroups per CU in total
             if (gx > cap) gx = cap;
             if (gx < 1) gx = 1;
+            // The fast kernel's tie certificate needs lambda*len to be 0 or comfortably normal.
+            bool fast_ok = sizeof(PenT) == 4 && !force_plain_kernel();
+            for (int i = 0; i < Lc; ++i) fast_ok = fast_ok && (lc.lam[i] == 0.0 || lc.lam[i] >= 5.4e-20);
+            if constexpr (sizeof(PenT) == 4) {
+                if (fast_ok) {
+                    const int r = launch_quant_fast<N>(mu, sg, n_per_ch, n_ch, table, pen, len_c, Lc, oi, oz, ob, E,
+                                                       vec_ok, st);
+                    if (r != VBQ_OK) return r;
+                    continue;
+                }
+            }
             hipLaunchKernelGGL((k_quant_flat<N, PenT>), dim3((unsigned)gx, (unsigned)n_ch), dim3(256), 0, st, mu, sg,
                                (long)n_per_ch, (int)n_ch, table, pen, len_c, Lc, oi, oz, ob, (long)E, vec_ok);
             VBQ_CHECK_LAUNCH("quant_flat");

@@ -1,0 +1,289 @@
+// K1, fast form for VBQ_MODE_F32 on channel-uniform workgroups (C == 1 or channel-major
+// planes): the hot kernel of the framework.   gfx950 / CDNA4 only.
+//
+// Same answers as k_quant_flat (vbq_quantize.hip), restructured so that the per-lambda work
+// is ~50 VALU ops per element instead of ~130:
+//
+//  * work in the COST domain: cost_j = fl(d_j + fl(lambda*len_j)) with d_j = fl(0.5*fl(t*t)).
+//    Negation is exact in IEEE arithmetic, so fl(-0.5 q - pen) == -fl(0.5 q + pen): the
+//    reference's first maximum of the score is the first minimum of the cost.
+//  * the two candidates of a bit level share their penalty, and rounding is monotone, so
+//    min(cost(L_n), cost(R_n)) = fl(min(dL, dR) + pen_n).  Phase A (once per element) keeps
+//    du_n = min(dL_n, dR_n) in registers (11 VGPRs) and parks one packed word per level in an
+//    LDS scratch column:  [ gap code:10 | rank of the other side:11 | rank of the better side:11 ].
+//  * phase B (per lambda): 11 adds with the wave-uniform penalties (SGPRs), a v_min3 tree for
+//    the best cost S, then sign(S - c_n) shifted into a bit mask (v_alignbit) -- two ops per
+//    level, no VCC traffic -- gives the set of levels that attain S.  One LDS read fetches the
+//    packed word of the first of them.
+//  * exactness of the tie rules.  The reference order is [L_0..L_N, R_1..R_N], first maximum
+//    wins (utils.py:401).  Two rare events are not decided by the fast path and are flagged:
+//      (a) more than one level attains S (a cross-level tie: an L of a deeper level beats an R
+//          of a shallower one);
+//      (b) the better side of the winning level is R and the two sides are so close that
+//          fl(dL + pen) may round onto fl(dR + pen), which would hand the win to L.  The 10-bit
+//          gap code is a lower bound of |dL - dR|; the flag is raised when it is <= 2^-21 * S.
+//    A wave with any flagged lane re-solves those lanes for that lambda with the literal
+//    21-candidate scan (exact_rank_scan).  Both events have probability ~1e-6 per solve.
+#include "vbq_common.h"
+
+namespace vbq {
+namespace {
+
+constexpr int kFastThreads = 256;
+constexpr int kFastNE = 4;
+
+__device__ __forceinline__ float dist_cost(float P, float mu, float sigma) {
+    const float d = __fsub_rn(P, mu);
+    const float t = __fdiv_rn(d, sigma);
+    const float q = __fmul_rn(t, t);
+    return __fmul_rn(0.5f, q);
+}
+
+template <int N>
+struct LevelInfo {
+    float dL, dR;
+    uint32_t posL, posR;
+};
+
+// One step of the descent (see vbq_quantize.hip, search_and_score): visits level n of the
+// level-major table, returns both neighbours' costs/slots and advances g.
+template <int N>
+__device__ __forceinline__ LevelInfo<N> descend(const float *tb, int n, float z, float sg, uint32_t &g) {
+    const int off = (1 << n) - 1;
+    const int m = 1 << n;
+    const uint32_t j = g;
+    const float pj = tb[off + j];
+    const bool below = pj < z;
+    LevelInfo<N> r;
+    if (n == 0) {
+        r.dL = r.dR = dist_cost(pj, z, sg);
+        r.posL = r.posR = 0;
+    } else {
+        int jo = below ? (int)j + 1 : (int)j - 1;
+        jo = jo < 0 ? 0 : (jo > m - 1 ? m - 1 : jo);
+        bool swap = false;
+        if (n == N && below && j == (uint32_t)(m - 1)) { jo = m - 2; swap = true; }
+        const float po = tb[off + jo];
+        const float dj = dist_cost(pj, z, sg);
+        const float dn = dist_cost(po, z, sg);
+        const bool j_is_left = below && !swap;
+        r.dL = j_is_left ? dj : dn;
+        r.dR = j_is_left ? dn : dj;
+        r.posL = j_is_left ? j : (uint32_t)jo;
+        r.posR = j_is_left ? (uint32_t)jo : j;
+    }
+    g = 2 * g + (below ? 1u : 0u);
+    return r;
+}
+
+// Literal restatement of the reference scan for ONE element and ONE lambda (slow path).
+template <int N>
+__device__ __noinline__ uint32_t exact_rank_scan(const float *tb, float z, float sg, const float *pen) {
+    uint32_t g = 0;
+    float bestL = 0.f, bestR = 0.f;
+    uint32_t rkL = 0, rkR = 0;
+    for (int n = 0; n <= N; ++n) {
+        const LevelInfo<N> li = descend<N>(tb, n, z, sg, g);
+        const float p = pen[n];
+        const float cL = __fadd_rn(li.dL, p);
+        if (n == 0 || cL < bestL) { bestL = cL; rkL = ((2 * li.posL + 1) << (N - n)) - 1; }
+        if (n >= 1) {
+            const float cR = __fadd_rn(li.dR, p);
+            if (n == 1 || cR < bestR) { bestR = cR; rkR = ((2 * li.posR + 1) << (N - n)) - 1; }
+        }
+    }
+    if (N == 0) return rkL;
+    return (bestL <= bestR) ? rkL : rkR;       // every L precedes every R in the reference order
+}
+
+template <int N, bool EXTRA>
+__global__ void __launch_bounds__(kFastThreads)
+k_quant_fast(const float *__restrict__ mu, const float *__restrict__ sg, long n_per_ch, int C,
+             const float *__restrict__ table, const float *__restrict__ pen, const float *__restrict__ len,
+             int L, uint16_t *__restrict__ out_idx, float *__restrict__ out_zhat,
+             float *__restrict__ out_bits, long E, int vec_ok) {
+    constexpr int T = table_size(N);
+    constexpr int N1 = N + 1;
+    constexpr int NE = kFastNE;
+    __shared__ float tb[T + 1];
+    __shared__ uint32_t scratch[N1 * NE * kFastThreads];
+    const int c = blockIdx.y;
+    for (int i = threadIdx.x; i < T; i += blockDim.x) tb[i] = table[(long)c * T + i];
+    __syncthreads();
+
+    const long base = (long)c * n_per_ch;
+    const long nquads = (n_per_ch + NE - 1) / NE;
+    const float *pen_c = pen + (long)c * N1;
+    const long pen_stride = (long)C * N1;
+
+    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < nquads; q += (long)gridDim.x * blockDim.x) {
+        const long i0 = q * NE;
+        const bool full = vec_ok && (i0 + NE <= n_per_ch);
+        float m4[NE], s4[NE];
+        if (full) {
+            const float4 mv = *reinterpret_cast<const float4 *>(mu + base + i0);
+            const float4 sv = *reinterpret_cast<const float4 *>(sg + base + i0);
+            m4[0] = mv.x; m4[1] = mv.y; m4[2] = mv.z; m4[3] = mv.w;
+            s4[0] = sv.x; s4[1] = sv.y; s4[2] = sv.z; s4[3] = sv.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < NE; ++k) {
+                const bool ok = i0 + k < n_per_ch;
+                m4[k] = ok ? mu[base + i0 + k] : 0.0f;
+                s4[k] = ok ? sg[base + i0 + k] : 1.0f;
+            }
+        }
+
+        // ---------------- phase A: descent, per-level best cost + packed side info ----------------
+        float du[NE][N1];
+        uint32_t g[NE];
+#pragma unroll
+        for (int k = 0; k < NE; ++k) g[k] = 0;
+#pragma unroll
+        for (int n = 0; n <= N; ++n) {
+#pragma unroll
+            for (int k = 0; k < NE; ++k) {
+                const LevelInfo<N> li = descend<N>(tb, n, m4[k], s4[k], g[k]);
+                const uint32_t rkL = ((2 * li.posL + 1) << (N - n)) - 1;
+                const uint32_t rkR = ((2 * li.posR + 1) << (N - n)) - 1;
+                const bool r_better = li.dR < li.dL;           // strict: on equal costs L keeps the level
+                du[k][n] = r_better ? li.dR : li.dL;
+                const uint32_t better = r_better ? rkR : rkL;
+                const uint32_t other = r_better ? rkL : rkR;
+                // lower bound of |dL - dR| in 10 bits (sign-less top bits of the float, minus one code)
+                const uint32_t gb = __float_as_uint(fabsf(__fsub_rn(li.dL, li.dR))) >> 21;
+                const uint32_t gcode = gb > 0 ? gb - 1 : 0;
+                scratch[(n * NE + k) * kFastThreads + threadIdx.x] = (gcode << 22) | (other << 11) | better;
+            }
+        }
+
+        // ---------------- phase B: one solve per lambda ----------------
+        for (int l = 0; l < L; ++l) {
+            const float *pp = pen_c + (long)l * pen_stride;
+            float p[N1];
+#pragma unroll
+            for (int n = 0; n < N1; ++n) p[n] = pp[n];
+            uint32_t rank[NE];
+            bool flagged[NE];
+            bool any_flag = false;
+            // The NE solves are written level-by-level across elements so that neighbouring
+            // instructions are independent (one element's chain alone issues ~1 op / 8 cycles).
+            float cst[NE][N1];
+#pragma unroll
+            for (int n = 0; n < N1; ++n)
+#pragma unroll
+                for (int k = 0; k < NE; ++k) cst[k][n] = __fadd_rn(du[k][n], p[n]);
+            float S[NE];
+#pragma unroll
+            for (int k = 0; k < NE; ++k) S[k] = cst[k][0];
+#pragma unroll
+            for (int n = 1; n + 1 < N1; n += 2)
+#pragma unroll
+                for (int k = 0; k < NE; ++k) S[k] = fminf(S[k], fminf(cst[k][n], cst[k][n + 1]));
+            if ((N1 & 1) == 0) {
+#pragma unroll
+                for (int k = 0; k < NE; ++k) S[k] = fminf(S[k], cst[k][N1 - 1]);
+            }
+            uint32_t ne[NE];                                    // bit (N-n) set <=> cost_n != S
+#pragma unroll
+            for (int k = 0; k < NE; ++k) ne[k] = 0;
+#pragma unroll
+            for (int n = 0; n < N1; ++n)
+#pragma unroll
+                for (int k = 0; k < NE; ++k)
+                    ne[k] = __builtin_amdgcn_alignbit(ne[k], __float_as_uint(__fsub_rn(S[k], cst[k][n])), 31);
+            uint32_t eq[NE], pk[NE];
+#pragma unroll
+            for (int k = 0; k < NE; ++k) {
+                eq[k] = ~ne[k] & ((1u << N1) - 1u);
+                const int n1 = __clz(eq[k]) - (31 - N);         // first (shallowest) level that attains S
+                pk[k] = scratch[(n1 * NE + k) * kFastThreads + threadIdx.x];
+            }
+#pragma unroll
+            for (int k = 0; k < NE; ++k) {
+                const uint32_t better = pk[k] & 0x7ffu, other = (pk[k] >> 11) & 0x7ffu;
+                const uint32_t gap_lo = (pk[k] >> 22) << 21;    // float bits of a lower bound of |dL-dR|
+                const bool multi = (eq[k] & (eq[k] - 1)) != 0;
+                const bool lr_close = (better > other) &&
+                                      (__uint_as_float(gap_lo) <= __fmul_rn(S[k], 4.76837158203125e-07f));
+                rank[k] = better;
+                flagged[k] = multi || lr_close;
+                any_flag = any_flag || flagged[k];
+            }
+            if (__any(any_flag)) {
+#pragma unroll
+                for (int k = 0; k < NE; ++k)
+                    if (flagged[k]) rank[k] = exact_rank_scan<N>(tb, m4[k], s4[k], pp);
+            }
+            const long o = (long)l * E + base + i0;
+            float zh[NE], bt[NE];
+            if (EXTRA) {
+#pragma unroll
+                for (int k = 0; k < NE; ++k) {
+                    const uint32_t kk = rank[k] + 1;
+                    const int tz = __builtin_ctz(kk);
+                    const int lvl = N - tz;
+                    const uint32_t pos = kk >> (tz + 1);
+                    zh[k] = tb[(1 << lvl) - 1 + pos];
+                    bt[k] = len ? len[((long)l * C + c) * N1 + lvl] : (float)lvl;
+                }
+            }
+            if (full) {
+                uint2 pk2;
+                pk2.x = rank[0] | (rank[1] << 16);
+                pk2.y = rank[2] | (rank[3] << 16);
+                *reinterpret_cast<uint2 *>(out_idx + o) = pk2;
+                if (EXTRA) {
+                    if (out_zhat) *reinterpret_cast<float4 *>(out_zhat + o) = make_float4(zh[0], zh[1], zh[2], zh[3]);
+                    if (out_bits) *reinterpret_cast<float4 *>(out_bits + o) = make_float4(bt[0], bt[1], bt[2], bt[3]);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < NE; ++k) {
+                    if (i0 + k < n_per_ch) {
+                        out_idx[o + k] = (uint16_t)rank[k];
+                        if (EXTRA) {
+                            if (out_zhat) out_zhat[o + k] = zh[k];
+                            if (out_bits) out_bits[o + k] = bt[k];
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+template <int N>
+int launch_quant_fast(const float *mu, const float *sg, int64_t n_per_ch, int32_t n_ch, const float *table,
+                      const float *pen, const float *len, int32_t L, uint16_t *out_idx, float *out_zhat,
+                      float *out_bits, int64_t E, int vec_ok, hipStream_t st) {
+    const int64_t nquads = (n_per_ch + kFastNE - 1) / kFastNE;
+    int64_t gx = (nquads + kFastThreads - 1) / kFastThreads;
+    // 3 workgroups per CU fit (53 KB of LDS each); keep every channel's share of the grid balanced
+    int64_t cap = (int64_t)256 * 3 * 4 / n_ch;
+    if (cap < 1) cap = 1;
+    if (gx > cap) gx = cap;
+    if (gx < 1) gx = 1;
+    const dim3 grid((unsigned)gx, (unsigned)n_ch), block(kFastThreads);
+    if (out_zhat || out_bits)
+        hipLaunchKernelGGL((k_quant_fast<N, true>), grid, block, 0, st, mu, sg, (long)n_per_ch, (int)n_ch, table, pen,
+                           len, (int)L, out_idx, out_zhat, out_bits, (long)E, vec_ok);
+    else
+        hipLaunchKernelGGL((k_quant_fast<N, false>), grid, block, 0, st, mu, sg, (long)n_per_ch, (int)n_ch, table, pen,
+                           len, (int)L, out_idx, out_zhat, out_bits, (long)E, vec_ok);
+    VBQ_CHECK_LAUNCH("quant_fast");
+    return VBQ_OK;
+}
+
+template int launch_quant_fast<10>(const float *, const float *, int64_t, int32_t, const float *, const float *,
+                                   const float *, int32_t, uint16_t *, float *, float *, int64_t, int, hipStream_t);
+template int launch_quant_fast<8>(const float *, const float *, int64_t, int32_t, const float *, const float *,
+                                  const float *, int32_t, uint16_t *, float *, float *, int64_t, int, hipStream_t);
+template int launch_quant_fast<6>(const float *, const float *, int64_t, int32_t, const float *, const float *,
+                                  const float *, int32_t, uint16_t *, float *, float *, int64_t, int, hipStream_t);
+template int launch_quant_fast<4>(const float *, const float *, int64_t, int32_t, const float *, const float *,
+                                  const float *, int32_t, uint16_t *, float *, float *, int64_t, int, hipStream_t);
+
+}  // namespace vbq

@@ -54,7 +54,9 @@ def _rows_channels(shape, layout):
 
 def quantize(mu: torch.Tensor, sigma: torch.Tensor, table_lm: torch.Tensor, lambdas: Sequence[float], *,
              N: int = 10, level_len: Optional[torch.Tensor] = None, layout="bc", mode="f32",
-             want_zhat: bool = False, want_bits: bool = False):
+             want_zhat: bool = False, want_bits: bool = False, out_idx: Optional[torch.Tensor] = None,
+             out_zhat: Optional[torch.Tensor] = None, out_bits: Optional[torch.Tensor] = None,
+             workspace: Optional[torch.Tensor] = None):
     """K1 (vbq_quantize_f32).  mu, sigma: f32 [rows, C] (layout 'bc') / [C, rows] ('cb') / [n] (C = 1).
     table_lm: f32 [C, T] level-major.  level_len: optional f32 [L, C, N+1].
     Returns idx u16 [L, *mu.shape] and, when asked, zhat / bits f32 of the same shape."""
@@ -77,11 +79,26 @@ def quantize(mu: torch.Tensor, sigma: torch.Tensor, table_lm: torch.Tensor, lamb
         if tuple(level_len.shape) != (L, Cc, N + 1):
             raise ValueError(f"level_len shape {tuple(level_len.shape)} != {(L, Cc, N + 1)}")
     h = _lib.lib()
-    idx = torch.empty((L,) + tuple(mu.shape), dtype=torch.uint16, device=mu.device)
-    zhat = torch.empty((L,) + tuple(mu.shape), dtype=torch.float32, device=mu.device) if want_zhat else None
-    bits = torch.empty((L,) + tuple(mu.shape), dtype=torch.float32, device=mu.device) if want_bits else None
+    oshape = (L,) + tuple(mu.shape)
+
+    def _out(given, dtype, want, name):
+        if given is not None:
+            if tuple(given.shape) != oshape or given.dtype != dtype or not given.is_cuda or not given.is_contiguous():
+                raise ValueError(f"{name}: expected a contiguous {dtype} device tensor of shape {oshape}")
+            return given
+        return torch.empty(oshape, dtype=dtype, device=mu.device) if want else None
+
+    idx = _out(out_idx, torch.uint16, True, "out_idx")
+    zhat = _out(out_zhat, torch.float32, want_zhat, "out_zhat")
+    bits = _out(out_bits, torch.float32, want_bits, "out_bits")
+    want_zhat, want_bits = zhat is not None, bits is not None
     wsb = h.vbq_quantize_workspace_bytes(Cc, L, N)
-    ws = torch.empty(wsb, dtype=torch.uint8, device=mu.device)
+    ws = workspace if workspace is not None else torch.empty(wsb, dtype=torch.uint8, device=mu.device)
+    if ws.numel() * ws.element_size() < wsb or not ws.is_cuda:
+        raise ValueError(f"workspace must be a device tensor of at least {wsb} bytes")
+    if mu.numel() == 0:
+        out = (idx,) + ((zhat,) if want_zhat else ()) + ((bits,) if want_bits else ())
+        return out if len(out) > 1 else idx
     check(h.vbq_quantize_f32(_ptr(mu), _ptr(sigma), rows, Cc, layout, _ptr(table_lm), _ptr(level_len),
                              _doubles(lambdas), L, N, mode, _ptr(idx), _ptr(zhat), _ptr(bits), _ptr(ws), wsb,
                              _stream(mu)), "vbq_quantize_f32")
