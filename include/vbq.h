@@ -110,13 +110,13 @@ int vbq_quantize_f32(const float *d_mu, const float *d_sigma, int64_t n_rows, in
  *   d_P     f32 [M][n_elems] candidate code points (n_elems = B*K flattened).
  *   d_len   f32 [M][n_elems], or [n_lambda][M][n_elems] when len_per_lambda != 0
  *           (the 4-D stack of utils.py:393-394).
- *   d_out_j   optional u8  [n_lambda][n_elems] winning candidate (first maximum);
+ *   d_out_j   optional i32 [n_lambda][n_elems] winning candidate (first maximum);
  *   d_out_zhat / d_out_bits   optional f32 [n_lambda][n_elems]   (utils.py:414-415).
  * ---------------------------------------------------------------------------------- */
 int vbq_argmax_candidates_f32(const float *d_P, const float *d_len, int32_t len_per_lambda,
                               const float *d_mu, const float *d_sigma, int64_t n_elems,
                               const double *h_lambdas, int32_t n_lambda, int32_t M, int32_t mode,
-                              uint8_t *d_out_j, float *d_out_zhat, float *d_out_bits, void *stream);
+                              int32_t *d_out_j, float *d_out_zhat, float *d_out_bits, void *stream);
 
 /* ----------------------------------------------------------------------------------
  * K1n  Notebook solve.  Replaces compress_coordinates(means, stds, beta, bitlengths)

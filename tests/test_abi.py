@@ -1,0 +1,64 @@
+"""The C-ABI library loads on a CPU-only host and exports exactly what include/vbq.h declares."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "vbq.h")
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(vbq_[a-z0-9_]+)\s*\(", src)))
+
+
+@pytest.fixture(scope="module")
+def built_lib():
+    from vbq_amd import build
+    return build.build_hip()
+
+
+def test_header_declares_the_expected_entry_points():
+    names = declared_functions()
+    for must in ("vbq_quantize_f32", "vbq_quantize_notebook_f64", "vbq_histogram_u16", "vbq_moments_f32",
+                 "vbq_gather_f32", "vbq_argmax_candidates_f32", "vbq_bmshj_cdf_pdf_f32", "vbq_bmshj_icdf_step_f32",
+                 "vbq_last_error", "vbq_abi_version"):
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol(built_lib):
+    out = subprocess.run(["nm", "-D", "--defined-only", built_lib], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r"\bT (vbq_[a-z0-9_]+)", out))
+    assert set(declared_functions()) <= exported, sorted(set(declared_functions()) - exported)
+    # and nothing but the C-ABI leaks out with C linkage
+    assert all(n in declared_functions() for n in exported), sorted(exported - set(declared_functions()))
+
+
+def test_ctypes_binding_matches_header(built_lib):
+    from vbq_amd import _lib
+    assert sorted(_lib.SIGNATURES) == declared_functions()
+    h = _lib.lib()
+    assert h.vbq_abi_version() == 1
+    assert isinstance(h.vbq_device_count(), int)
+    # argument validation happens before any device work: callable without a GPU
+    assert h.vbq_quantize_workspace_bytes(256, 32, 10) >= 256 * 32 * 11 * 4
+    r = h.vbq_quantize_f32(None, None, 5, 1, 0, None, None, None, 1, 10, 0, None, None, None, None, 0, None)
+    assert r == -1 and b"null pointer" in h.vbq_last_error()
+    r = h.vbq_quantize_f32(None, None, 0, 1, 7, None, None, None, 1, 10, 0, None, None, None, None, 0, None)
+    assert r == -1 and b"layout" in h.vbq_last_error()
+    r = h.vbq_histogram_u16(None, -1, 1, 0, 1, 10, None, None)
+    assert r == -1
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from vbq_amd import _lib
+    monkeypatch.setattr(_lib, "_LIB", None)
+    monkeypatch.setenv("VBQ_HIP_LIBRARY", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.VBQError, match="not built"):
+        _lib.lib()
+    monkeypatch.delenv("VBQ_HIP_LIBRARY")
+    monkeypatch.setattr(_lib, "_LIB", None)
+    assert _lib.lib() is not None

@@ -1,0 +1,111 @@
+"""Host-side logic that needs no GPU: table index arithmetic, entropy-model arithmetic,
+quantizer state, argument validation and the refusal to run without a device."""
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vbq_oracle as O
+from vbq_amd import ChannelwisePriorCDFQuantizer, VBQError, entropy, ops, priors, tables, utils
+
+N = 10
+
+
+def test_table_index_arithmetic(golden):
+    assert np.array_equal(tables.dyadic_xi(N), golden("g1_xi_grid.npz")["xi"])
+    assert np.array_equal(tables.rank_of_slot(N), O.level_major_to_rank(N))
+    assert np.array_equal(tables.level_of_rank(N), O.levels_of_sorted_ranks(N))
+    assert np.array_equal(entropy.rank_levels(N), O.levels_of_sorted_ranks(N))
+    t = np.sort(np.random.default_rng(0).normal(size=(3, 2047)).astype(np.float32), axis=1)
+    assert np.array_equal(tables.level_major_to_sorted(tables.sorted_to_level_major(t)), t)
+
+
+def test_entropy_models_match_reference_arithmetic(golden):
+    """counts -> -log2(freq) in float32 exactly as quantizer.py:104-110 (pinned by golden G8)."""
+    g5, g8 = golden("g5_batch_quantize.npz"), golden("g8_corrected_lengths.npz")
+    lev = O.levels_of_sorted_ranks(N)
+    L, B, C = g5["bits_f32"].shape
+    # rank histogram whose level marginals are the golden pass-1 bit counts
+    counts = np.zeros((L, C, 2047), np.int64)
+    first_rank_of_level = np.array([np.argmax(lev == n) for n in range(N + 1)])
+    for l in range(L):
+        for c in range(C):
+            bc = np.bincount(g5["bits_f32"][l][:, c], minlength=N + 1)
+            counts[l, c, first_rank_of_level] = bc
+    ct = torch.from_numpy(counts)
+    lc = entropy.level_counts_from_counts(ct, N).numpy()
+    assert np.array_equal(lc[3, 1], np.bincount(g5["bits_f32"][3][:, 1], minlength=N + 1))
+    assert np.array_equal(entropy.neg_log2_freq(lc, 1), g8["raw_models"])
+    ll = entropy.level_lengths_from_counts(ct, N, 1).numpy()
+    want = np.stack([O.corrected_level_lengths(N, m).T for m in g8["raw_models"]])
+    assert np.array_equal(ll, want)
+
+
+def test_quantizer_tables_state_and_pickle(golden):
+    g = golden("g5_batch_quantize.npz")
+    C = g["mu"].shape[1]
+    q = ChannelwisePriorCDFQuantizer(C, N)
+    assert q.quantization_levels == 2047 and q.entropy_models is None
+    q.build_code_points(priors.FactoredGaussianPrior(g["ch_mean"], g["ch_std"]))
+    orc = O.ChannelwiseOracle(C, N)
+    orc.build_code_points(O.factored_gaussian_icdf(g["ch_mean"], g["ch_std"]))
+    assert np.array_equal(q.all_code_points, g["all_code_points"])
+    assert np.array_equal(q.code_points_by_channel, orc.by_channel)
+    assert np.array_equal(q._search_grids, orc.grids)
+    assert len(q.code_points_by_bits) == C and len(q.code_points_by_bits[0][7]) == 128
+    q.raw_code_length_entropy_models = {0.5: np.zeros((C, N + 1), np.float32)}
+    q.entropy_models = {0.5: np.zeros((C, 2047), np.float32), 0.25: np.zeros((C, 2047), np.float32)}
+    q2 = pickle.loads(pickle.dumps(q))                      # post_process.py:106-107,163-164
+    assert q2.lambs == [0.25, 0.5] and np.array_equal(q2.all_code_points, q.all_code_points)
+
+    class Bad:
+        def inverse_cdf(self, xi):
+            out = O.standard_gaussian_icdf(xi)
+            out[5] += 10.0
+            return out
+    with pytest.raises(ValueError, match="monotone"):
+        ChannelwisePriorCDFQuantizer(C, N).build_code_points(Bad())
+
+
+def test_gaussian_priors():
+    xi = np.repeat(tables.dyadic_xi(4)[:, None], 2, axis=1)
+    p = priors.FactoredGaussianPrior(np.array([0.0, 1.0]), np.array([1.0, 2.0]))
+    assert np.array_equal(p.inverse_cdf(xi), O.factored_gaussian_icdf(np.array([0.0, 1.0]), np.array([1.0, 2.0]))(xi))
+    assert np.array_equal(priors.StandardGaussianPrior.inverse_cdf(xi), O.standard_gaussian_icdf(xi))
+    z = np.array([[0.3, -0.2]])
+    assert np.allclose(p.pdf(z), np.exp(p.logpdf(z)))
+    b = priors.BMSHJ2018Prior(3, init_scale=10.0, seed=1)
+    mats, bias, fac = O.BMSHJ2018Oracle.init_params(3, init_scale=10.0)
+    assert all(np.array_equal(a, m) for a, m in zip(b.matrices, mats))       # learned_prior.py:38 init constant
+    assert priors.pack_bmshj_params(*b.effective_parameters()).shape == (3, 43)
+    with pytest.raises(ValueError):
+        priors.BMSHJ2018Prior(3, dims=(3, 3))
+
+
+def test_no_cpu_fallback():
+    """Ops refuse host tensors instead of computing on the CPU."""
+    x = torch.zeros(8)
+    tab = torch.zeros(1, 2047)
+    with pytest.raises(VBQError, match="no CPU implementation|only run on a ROCm device"):
+        ops.quantize(x, x + 1, tab, [1.0])
+    with pytest.raises(VBQError):
+        ops.histogram(torch.zeros((1, 8), dtype=torch.uint16), 1)
+    if not torch.cuda.is_available():
+        with pytest.raises(VBQError):
+            utils.batch_quantize_indep_dims((1, 2), np.zeros((3, 1, 2), np.float32), np.zeros((3, 1, 2), np.float32),
+                                            utils.curry_normal_logpdf(np.zeros(2, np.float32), np.ones(2, np.float32),
+                                                                      ignore_const=True), [1.0])
+        q = ChannelwisePriorCDFQuantizer(1, N)
+        q.build_code_points(priors.StandardGaussianPrior())
+        with pytest.raises(VBQError):
+            q.compress_batch_channel_latents(np.zeros((4, 1), np.float32), np.ones((4, 1), np.float32), [1.0])
+
+
+def test_utils_argument_contract():
+    f = utils.curry_normal_logpdf(np.float32([0.1, 0.2]), np.float32([1, 2]), ignore_const=True)
+    z = np.float32([[0.5, 0.6]])
+    assert np.array_equal(f(z), -0.5 * ((z - np.float32([0.1, 0.2])) / np.float32([1, 2])) ** 2)   # utils.py:319-320
+    assert utils.n_bit_binary_floats(2) == [0.125, 0.375, 0.625, 0.875]
+    with pytest.raises(TypeError):
+        utils.batch_quantize_indep_dims((1, 2), np.zeros((3, 1, 2)), np.zeros((3, 1, 2)), lambda z: z, [1.0])

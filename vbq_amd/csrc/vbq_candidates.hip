@@ -16,7 +16,7 @@ template <bool F64>
 __global__ void __launch_bounds__(256)
 k_argmax_candidates(const float *__restrict__ P, const float *__restrict__ len, long len_lambda_stride,
                     const float *__restrict__ mu, const float *__restrict__ sg, long E, Lam8 lc, int Lc, int M,
-                    uint8_t *__restrict__ out_j, float *__restrict__ out_z, float *__restrict__ out_b) {
+                    int32_t *__restrict__ out_j, float *__restrict__ out_z, float *__restrict__ out_b) {
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (long)gridDim.x * blockDim.x) {
         const float m = mu[e], s = sg[e];
         float bestf[kLamChunk];
@@ -48,7 +48,7 @@ k_argmax_candidates(const float *__restrict__ P, const float *__restrict__ len, 
         for (int l = 0; l < kLamChunk; ++l) {
             if (l < Lc) {
                 const long o = (long)l * E + e;
-                if (out_j) out_j[o] = (uint8_t)bj[l];
+                if (out_j) out_j[o] = bj[l];
                 if (out_z) out_z[o] = P[(long)bj[l] * E + e];
                 if (out_b) out_b[o] = len[l * len_lambda_stride + (long)bj[l] * E + e];
             }
@@ -62,12 +62,12 @@ k_argmax_candidates(const float *__restrict__ P, const float *__restrict__ len, 
 extern "C" int vbq_argmax_candidates_f32(const float *d_P, const float *d_len, int32_t len_per_lambda,
                                          const float *d_mu, const float *d_sigma, int64_t n_elems,
                                          const double *h_lambdas, int32_t n_lambda, int32_t M, int32_t mode,
-                                         uint8_t *d_out_j, float *d_out_zhat, float *d_out_bits, void *stream) {
+                                         int32_t *d_out_j, float *d_out_zhat, float *d_out_bits, void *stream) {
     using namespace vbq;
     VBQ_REQUIRE(d_P && d_len && d_mu && d_sigma && h_lambdas, VBQ_ERR_INVALID_ARGUMENT,
                 "vbq_argmax_candidates_f32: null pointer argument");
-    VBQ_REQUIRE(n_elems >= 0 && n_lambda >= 1 && M >= 1 && M <= 255, VBQ_ERR_INVALID_ARGUMENT,
-                "vbq_argmax_candidates_f32: bad sizes n_elems=%lld n_lambda=%d M=%d (1 <= M <= 255)",
+    VBQ_REQUIRE(n_elems >= 0 && n_lambda >= 1 && M >= 1 && M <= 65535, VBQ_ERR_INVALID_ARGUMENT,
+                "vbq_argmax_candidates_f32: bad sizes n_elems=%lld n_lambda=%d M=%d (1 <= M <= 65535)",
                 (long long)n_elems, n_lambda, M);
     VBQ_REQUIRE(mode == VBQ_MODE_F32 || mode == VBQ_MODE_F64_SCORE, VBQ_ERR_INVALID_ARGUMENT,
                 "vbq_argmax_candidates_f32: unknown mode %d", mode);
@@ -81,7 +81,7 @@ extern "C" int vbq_argmax_candidates_f32(const float *d_P, const float *d_len, i
         Lam8 lc;
         for (int i = 0; i < kLamChunk; ++i) lc.lam[i] = i < Lc ? h_lambdas[l0 + i] : 0.0;
         const float *len = d_len + (int64_t)l0 * lstride;
-        uint8_t *oj = d_out_j ? d_out_j + (int64_t)l0 * n_elems : nullptr;
+        int32_t *oj = d_out_j ? d_out_j + (int64_t)l0 * n_elems : nullptr;
         float *oz = d_out_zhat ? d_out_zhat + (int64_t)l0 * n_elems : nullptr;
         float *ob = d_out_bits ? d_out_bits + (int64_t)l0 * n_elems : nullptr;
         if (mode == VBQ_MODE_F32)

@@ -1,0 +1,74 @@
+"""Element-axis sharding across the GPUs of one node (one process per GPU, RCCL over xGMI).
+
+Every (mu, sigma) element is solved independently (utils.py:401 is a per-element argmax), so
+the rows are split contiguously across ranks and the only exchange of the whole pipeline is the
+sum of the per-rank histograms (quantizer.py:104-105,138-140) and moment accumulators
+(ipynb:374): integer / f64 all-reduces of a few hundred KB to a few tens of MB.  Integer sums
+make the resulting entropy models independent of the number of ranks.
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: Optional[str] = None):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*; returns
+    (rank, world, device).  backend "nccl" is RCCL on ROCm; "gloo" is used on CPU-only hosts."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    use_gpu = torch.cuda.is_available()
+    device = torch.device("cuda", local) if use_gpu else torch.device("cpu")
+    if use_gpu:
+        torch.cuda.set_device(local)
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group(backend or ("nccl" if use_gpu else "gloo"), rank=rank, world_size=world)
+    return rank, world, device
+
+
+def shard_rows(n_rows: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous [start, stop) of this rank's rows; sizes differ by at most one."""
+    base, rem = divmod(n_rows, world)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+def allreduce_sum_(t: torch.Tensor, group=None) -> torch.Tensor:
+    """In-place SUM over ranks (no-op without an initialised process group)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
+def global_counts(local_counts: torch.Tensor, group=None) -> torch.Tensor:
+    """int64 [L, C, T] rank histograms -> global histogram on every rank."""
+    assert local_counts.dtype == torch.int64
+    return allreduce_sum_(local_counts, group)
+
+
+def global_empirical_std(local_moments: torch.Tensor, n_local: int, group=None) -> np.ndarray:
+    """f64 [C, 2] = (sum x, sum x^2) of this shard -> sqrt(mean x^2) per channel over all shards
+    (ipynb:374 computed globally)."""
+    buf = torch.cat([local_moments.reshape(-1), torch.tensor([float(n_local)], dtype=torch.float64,
+                                                             device=local_moments.device)])
+    allreduce_sum_(buf, group)
+    m = buf[:-1].reshape(local_moments.shape).cpu().numpy()
+    return np.sqrt(m[:, 1] / float(buf[-1].item()))
+
+
+def entropy_models_from_local_counts(local_counts: torch.Tensor, N: int, add_n_smoothing=1, group=None):
+    """The collective + finish of build_entropy_models for one pass: returns
+    (raw_length_models f32 [L, C, N+1], code_point_models f32 [L, C, T]) computed from the
+    GLOBAL histogram; identical on every rank and for every world size."""
+    from . import entropy
+    g = global_counts(local_counts.clone(), group)
+    raw = entropy.neg_log2_freq(entropy.level_counts_from_counts(g, N), add_n_smoothing)
+    full = entropy.neg_log2_freq(g, add_n_smoothing)
+    return raw, full

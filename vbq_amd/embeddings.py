@@ -1,0 +1,102 @@
+"""Word-embedding VBQ with the notebook's call surface
+(word-embeddings/compress-trained-word-embeddings.ipynb cells 25-30, JSON lines 373-473).
+
+    empirical_std(vecs)                          ipynb:373-374   (K3 moment pass)
+    make_code_book(std, max_codepoint_length)    ipynb:383-390   (host: scipy ppf, as the notebook)
+    compress_coordinates(means, stds, beta, ...) ipynb:429-443   (K1n)
+    empirical_entropy(values)                    ipynb:452-455   (K2 histogram when indices are given)
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import ops
+from ._lib import VBQError
+from .tables import rank_of_slot
+
+
+def _device():
+    if not torch.cuda.is_available():
+        raise VBQError("no ROCm device visible: vbq_amd.embeddings has no CPU implementation")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _dev(a, dtype=torch.float32):
+    t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(a)))
+    return t.to(_device(), dtype).contiguous()
+
+
+def empirical_std(vecs) -> np.float32:
+    """sqrt(mean(x**2)) (ipynb:374).  Sums are accumulated in f64 on the GPU (the notebook's f32
+    pairwise mean differs from this by rounding only; tolerance 1e-6 relative)."""
+    x = _dev(vecs).reshape(-1)
+    m = ops.moments(x)
+    return np.float32(np.sqrt(float(m[0, 1].item()) / x.numel()))
+
+
+def make_code_book(std, max_codepoint_length: int = 10):
+    """ipynb:383-390: (codepoints f64 [T] level-major, lengths int64 [T])."""
+    import scipy.stats
+    pts, lens = [], []
+    for length in range(max_codepoint_length + 1):
+        xi = np.arange(0.5 ** (length + 1), 1, 0.5 ** length)
+        pts.append(scipy.stats.norm.ppf(xi, scale=std))
+        lens.append(np.full(xi.shape, length, dtype=np.int64))
+    return np.concatenate(pts), np.concatenate(lens)
+
+
+def compress_coordinates_sweep(means, stds, betas: Sequence[float], codepoints, *, want_values=True):
+    """All betas in one launch.  Returns (idx u16 [n_beta, *shape] device tensor, values f32 or None)."""
+    N = int(np.log2(len(codepoints) + 1)) - 1
+    return ops.quantize_notebook(_dev(means), _dev(stds), _dev(codepoints, torch.float64), [float(b) for b in betas],
+                                 N=N, want_values=want_values)
+
+
+def compress_coordinates(means, stds, beta, bitlengths=None, codepoints=None):
+    """ipynb:429-443.  `codepoints` replaces the notebook's global of the same name; `bitlengths`
+    must be the level of every slot (the only table the notebook ever passes) and is validated.
+    Returns the quantized array (f32, shaped like `means`; NumPy in -> NumPy out)."""
+    if codepoints is None:
+        raise ValueError("pass codepoints=... (the notebook reads a global; make_code_book() builds it)")
+    N = int(np.log2(len(codepoints) + 1)) - 1
+    if bitlengths is not None:
+        want = np.concatenate([np.full(2 ** n, n) for n in range(N + 1)])
+        if not np.array_equal(np.asarray(bitlengths), want):
+            raise ValueError("bitlengths must equal the bit level of each level-major slot")
+    _, val = compress_coordinates_sweep(means, stds, [beta], codepoints)
+    out = val[0]
+    return out if isinstance(means, torch.Tensor) else out.cpu().numpy()
+
+
+def entropy_from_counts(counts) -> float:
+    c = np.asarray(counts.cpu().numpy() if isinstance(counts, torch.Tensor) else counts, dtype=np.float64).ravel()
+    c = c[c > 0]
+    tot = c.sum()
+    return float(tot * np.log2(tot) - c.dot(np.log2(c)))
+
+
+def entropy_from_indices(idx: torch.Tensor, N: int = 10):
+    """ipynb:452-455 on rank indices: one K2 histogram per beta.  idx: u16 [n_beta, ...]."""
+    cnt = ops.histogram(idx.reshape(idx.shape[0], -1), 1, N=N)
+    return [entropy_from_counts(cnt[i]) for i in range(cnt.shape[0])]
+
+
+def empirical_entropy(values) -> float:
+    """ipynb:452-455 on an arbitrary value array (generic multiset count via torch.unique)."""
+    v = _dev(values).reshape(-1)
+    _, counts = torch.unique(v, return_counts=True)
+    return entropy_from_counts(counts)
+
+
+def test_beta(means, stds, beta, codepoints, prediction_ranks=None):
+    """ipynb:464-473 (the notebook passes the (array, None) tuple on; the array is used here)."""
+    idx, val = compress_coordinates_sweep(means, stds, [beta], codepoints)
+    compressed = val[0]
+    bits = entropy_from_indices(idx, N=int(np.log2(len(codepoints) + 1)) - 1)[0]
+    if prediction_ranks is None:
+        return compressed, bits
+    ranks = np.asarray(prediction_ranks(compressed.cpu().numpy()))
+    return np.average(1 / (1 + ranks)), np.sum(ranks == 0) / len(ranks), np.sum(ranks < 10) / len(ranks), bits

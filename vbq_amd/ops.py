@@ -198,7 +198,7 @@ def argmax_candidates(P: torch.Tensor, lens: torch.Tensor, mu: torch.Tensor, sig
     n = mu.numel()
     zhat = torch.empty((L,) + tuple(mu.shape), dtype=torch.float32, device=mu.device)
     bits = torch.empty_like(zhat)
-    j = torch.empty((L,) + tuple(mu.shape), dtype=torch.uint8, device=mu.device) if want_j else None
+    j = torch.empty((L,) + tuple(mu.shape), dtype=torch.int32, device=mu.device) if want_j else None
     check(_lib.lib().vbq_argmax_candidates_f32(_ptr(P), _ptr(lens), int(per_lambda), _ptr(mu), _ptr(sigma), n,
                                                _doubles(lambdas), L, M, mode, _ptr(j), _ptr(zhat), _ptr(bits),
                                                _stream(mu)), "vbq_argmax_candidates_f32")

@@ -1,5 +1,61 @@
-"""Priors that produce code-point tables (stub, filled in below)."""
+"""Priors whose inverse CDF defines the code-point tables.
+
+    StandardGaussianPrior / FactoredGaussianPrior   img-compression/vae_models.py:14-43
+    BMSHJ2018Prior                                  img-compression/learned_prior.py:6-334
+
+The Gaussian priors are table builders: 2047*C calls of scipy's ppf on the host, exactly as the
+reference does.  BMSHJ2018Prior evaluates cdf / pdf / logpdf and the bisection inverse CDF with
+the K4 HIP kernels.  Its TF numerics are not reproducible here (no TensorFlow, no stored table
+in the reference), so parity for this class is "unpinned": tests check self-consistency and
+agreement with the NumPy restatement in oracle/ to float tolerance.
+"""
+from __future__ import annotations
+
 import numpy as np
+import torch
+
+from . import ops
+from ._lib import VBQError
+
+log2pi = np.log(2.0 * np.pi).astype("float32")
+
+
+def log_normal_pdf(sample, mean, logvar):
+    """vae_models.py:9-11."""
+    return -0.5 * ((sample - mean) ** 2.0 * np.exp(-logvar) + logvar + log2pi)
+
+
+class StandardGaussianPrior:
+    @staticmethod
+    def logpdf(z):
+        return log_normal_pdf(z, 0.0, 0.0)
+
+    @staticmethod
+    def pdf(z):
+        return np.exp(StandardGaussianPrior.logpdf(z))
+
+    @staticmethod
+    def inverse_cdf(xi):
+        from scipy.stats import norm
+        return norm.ppf(xi)
+
+
+class FactoredGaussianPrior:
+    def __init__(self, mean, std):
+        self.mean = np.asarray(mean)
+        self.std = np.asarray(std)
+        self.logvar = 2 * np.log(self.std)
+
+    def logpdf(self, z):
+        return log_normal_pdf(z, self.mean, self.logvar)
+
+    def pdf(self, z):
+        return np.exp(self.logpdf(z))
+
+    def inverse_cdf(self, xi):
+        from scipy.stats import norm
+        assert xi.shape[-1] == len(self.mean)
+        return norm.ppf(xi, loc=self.mean, scale=self.std)
 
 
 def pack_bmshj_params(matrices, biases, factors) -> np.ndarray:
@@ -14,3 +70,128 @@ def pack_bmshj_params(matrices, biases, factors) -> np.ndarray:
     out = np.concatenate(parts, axis=1)
     assert out.shape == (C, 43)
     return np.ascontiguousarray(out)
+
+
+def _device():
+    if not torch.cuda.is_available():
+        raise VBQError("no ROCm device visible: BMSHJ2018Prior has no CPU implementation")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+class BMSHJ2018Prior:
+    """Per-channel non-parametric CDF of Balle et al. 2018 (learned_prior.py:6-58).
+
+    Raw variables matrix_i / bias_i / factor_i are kept as float32 NumPy arrays with the
+    reference's shapes; softplus / tanh are applied when a method is called (the reference
+    applies them once in __init__, learned_prior.py:43,57 -- SURVEY 7.2 item 7)."""
+
+    def __init__(self, channels, dims=(3, 3, 3), init_scale=10.0, seed=None, **kwargs):
+        self._channels = int(channels)
+        self._init_scale = float(init_scale)
+        self._dims = tuple(int(f) for f in dims)
+        if self._dims != (3, 3, 3):
+            raise ValueError("the HIP kernels are built for dims=(3, 3, 3) (the reference default and the only "
+                             "setting post_process.py:78 uses)")
+        d = (1,) + self._dims + (1,)
+        scale = self._init_scale ** (1 / (len(self._dims) + 1))
+        rng = np.random.default_rng(seed)
+        self.matrices, self.biases, self.factors = [], [], []
+        for i in range(len(self._dims) + 1):
+            init = np.log(np.expm1(1 / scale / d[i + 1]))
+            self.matrices.append(np.full((self._channels, d[i + 1], d[i]), init, dtype=np.float32))
+            self.biases.append(rng.uniform(-0.5, 0.5, (self._channels, d[i + 1], 1)).astype(np.float32))
+            if i < len(self._dims):
+                self.factors.append(np.zeros((self._channels, d[i + 1], 1), dtype=np.float32))
+        self._params_dev = None
+
+    init_scale = property(lambda self: self._init_scale)
+    dims = property(lambda self: self._dims)
+    channels = property(lambda self: self._channels)
+
+    # ---- weights ----------------------------------------------------------------------------
+    def get_weights(self):
+        out = []
+        for i in range(4):
+            out += [self.matrices[i], self.biases[i]] + ([self.factors[i]] if i < 3 else [])
+        return out
+
+    def set_weights(self, weights):
+        it = iter(weights)
+        for i in range(4):
+            self.matrices[i] = np.asarray(next(it), np.float32)
+            self.biases[i] = np.asarray(next(it), np.float32)
+            if i < 3:
+                self.factors[i] = np.asarray(next(it), np.float32)
+        self._params_dev = None
+
+    def save_weights(self, path):
+        np.savez(path, *self.get_weights(), channels=self._channels, init_scale=self._init_scale)
+
+    def load_weights(self, path):
+        z = np.load(path)
+        self.set_weights([z[f"arr_{i}"] for i in range(11)])
+
+    def effective_parameters(self):
+        sp = [np.logaddexp(np.float32(0), m).astype(np.float32) for m in self.matrices]       # softplus (:43)
+        return sp, self.biases, [np.tanh(f).astype(np.float32) for f in self.factors]       # tanh (:57)
+
+    def _params(self):
+        if self._params_dev is None:
+            self._params_dev = torch.from_numpy(pack_bmshj_params(*self.effective_parameters())).to(_device())
+        return self._params_dev
+
+    # ---- evaluation (learned_prior.py:109-171, 235-334) ---------------------------------------
+    def _x(self, inputs):
+        t = inputs if isinstance(inputs, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(inputs)))
+        t = t.to(_device(), torch.float32).contiguous()
+        assert t.shape[-1] == self._channels, \
+            "Innermost dimension of inputs = %d, does not match number of channels = %d" % (t.shape[-1], self._channels)
+        return t
+
+    def _ret(self, t, like):
+        return t if isinstance(like, torch.Tensor) else t.cpu().numpy()
+
+    def cdf(self, inputs, stop_gradient=None):
+        return self._ret(ops.bmshj_cdf_pdf(self._params(), self._x(inputs), cdf=True, pdf=False)[0], inputs)
+
+    def pdf(self, inputs, stop_gradient=False):
+        return self._ret(ops.bmshj_cdf_pdf(self._params(), self._x(inputs), cdf=False, pdf=True)[1], inputs)
+
+    def logpdf(self, inputs, stop_gradient=False):
+        return self._ret(ops.bmshj_cdf_pdf(self._params(), self._x(inputs), cdf=False, pdf=False, logpdf=True)[2], inputs)
+
+    def cdf_pdf(self, inputs, stop_gradient=False):
+        c, p, _ = ops.bmshj_cdf_pdf(self._params(), self._x(inputs), cdf=True, pdf=True)
+        return self._ret(c, inputs), self._ret(p, inputs)
+
+    def inverse_cdf(self, xi, method="bisection", max_iterations=1000, tol=1e-9, **kwargs):
+        """learned_prior.py:173-218: global bracket doubling, masked bisection, the reference's
+        stopping rule (all mid values exactly 0, or the smallest bracket <= tol)."""
+        if method != "bisection":
+            raise NotImplementedError
+        xi_t = self._x(xi)
+        params = self._params()
+        left = torch.full_like(xi_t, -1.0)
+        right = torch.full_like(xi_t, 1.0)
+
+        def f(z):
+            return ops.bmshj_cdf_pdf(params, z, cdf=True, pdf=False)[0] - xi_t
+        while not bool(torch.all(f(left) < 0)):
+            left = left * 2
+        while not bool(torch.all(f(right) > 0)):
+            right = right * 2
+        mid = torch.empty_like(xi_t)
+        flags = torch.empty(2, dtype=torch.int32, device=xi_t.device)
+        init = torch.tensor([0, 0x7F800000], dtype=torch.int32, device=xi_t.device)
+        self.last_iterations = 0
+        for i in range(max_iterations):
+            flags.copy_(init)
+            ops.bmshj_icdf_step(params, xi_t, left, right, mid, flags)
+            nz, wbits = flags.cpu().numpy().astype(np.uint32)
+            self.last_iterations = i
+            width = np.array([wbits], dtype=np.uint32).view(np.float32)[0]
+            if nz == 0 or width <= np.float32(tol):
+                break
+        if kwargs.get("return_np", False) or not isinstance(xi, torch.Tensor):
+            return mid.cpu().numpy()
+        return mid

@@ -1,0 +1,294 @@
+"""ChannelwisePriorCDFQuantizer with the reference's call surface
+(img-compression/quantizer.py:13-256), running on the HIP kernels.
+
+Same constructor, method names, argument meaning, returned dict layout and state attributes
+as the reference class, so `post_process.build_cdf_qzer` / `utils.evaluate_compression_quantizer`
+(post_process.py:99-107, utils.py:542-554) can use it unchanged.  What differs is inside:
+
+* the whole of get_all_N_bit_intervals -> candidate assembly -> batch_quantize_indep_dims ->
+  qidx lookup (quantizer.py:65-80, 156-188, 135/223) is ONE kernel launch (K1) for all lambdas;
+* per-channel bincounts (quantizer.py:104-105, 138-140) are one histogram launch (K2);
+* latents live on the GPU as channel-major planes [C, B]: every workgroup then works on one
+  channel -> one 8 KB code-point table in LDS and wave-uniform penalties.
+
+Arrays may be NumPy arrays or torch tensors; results are NumPy arrays (as in the reference,
+whose np.reshape moves everything to the host, quantizer.py:237) unless `return_np=False`.
+There is no CPU path: without the HIP extension and a ROCm device the methods raise.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import entropy as _entropy
+from . import ops
+from ._lib import VBQError
+
+
+def n_bit_binary_floats(n: int):
+    """utils.py:23-24."""
+    return [i * 2 ** (-n) + 2 ** (-n - 1) for i in range(2 ** n)]
+
+
+def _to_numpy(a):
+    if isinstance(a, torch.Tensor):
+        return a.detach().cpu().numpy()
+    if hasattr(a, "numpy") and not isinstance(a, np.ndarray):      # e.g. a TF eager tensor
+        return np.asarray(a.numpy())
+    return np.asarray(a)
+
+
+def _default_device():
+    if not torch.cuda.is_available():
+        raise VBQError("no ROCm device visible: the VBQ quantizer has no CPU implementation")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+class ChannelwisePriorCDFQuantizer:
+    def __init__(self, num_channels, max_bits_per_coord, float_type="float32", int_type="int32", device=None):
+        if float_type != "float32":
+            raise ValueError("only float_type='float32' is supported (the reference default, quantizer.py:14)")
+        self.max_bits_per_coord = int(max_bits_per_coord)
+        self.num_channels = int(num_channels)
+        self.float_type = float_type
+        self.int_type = int_type
+        self.quantization_levels = 2 ** (self.max_bits_per_coord + 1) - 1          # quantizer.py:20
+        self.raw_code_length_entropy_models = None
+        self.entropy_models = None
+        self.process_group = None          # set to a torch.distributed group to all-reduce the histograms
+        self._device = device
+        self._dev_cache: Dict[str, torch.Tensor] = {}
+
+    # ------------------------------------------------------------------ state / pickling
+    def __getstate__(self):
+        st = dict(self.__dict__)
+        st["_dev_cache"] = {}
+        st["_device"] = None
+        st["process_group"] = None
+        return st
+
+    def __setstate__(self, st):
+        self.__dict__.update(st)
+        self._dev_cache = {}
+
+    @property
+    def device(self):
+        if self._device is None:
+            self._device = _default_device()
+        return self._device
+
+    def _dev(self, name: str, builder):
+        t = self._dev_cache.get(name)
+        if t is None or t.device != self.device:
+            t = builder().to(self.device)
+            self._dev_cache[name] = t
+        return t
+
+    # ------------------------------------------------------------------ tables (quantizer.py:25-63)
+    def build_code_points(self, prior_model, **kwargs):
+        N, C = self.max_bits_per_coord, self.num_channels
+        all_bin_floats = np.hstack([n_bit_binary_floats(n) for n in range(N + 1)])
+        all_bin_floats_rep = np.repeat(all_bin_floats[:, None], C, axis=1)          # T x C
+        pts = _to_numpy(prior_model.inverse_cdf(all_bin_floats_rep, **kwargs))
+        if pts.shape != (self.quantization_levels, C):
+            raise ValueError(f"prior.inverse_cdf returned shape {pts.shape}, expected {(self.quantization_levels, C)}")
+        self.all_code_points = np.ascontiguousarray(pts.astype(np.float32).T)       # C x T, level-major
+        self.code_points_by_channel = np.sort(self.all_code_points, axis=1)         # MUST BE SORTED (:37)
+        self.code_points_by_bits = [[self.all_code_points[c, 2 ** n - 1: 2 ** (n + 1) - 1] for n in range(N + 1)]
+                                    for c in range(C)]
+        grids = np.empty((C, N + 1, 2 ** N), dtype=np.float32)
+        for c in range(C):
+            for n in range(N + 1):
+                lvl = self.code_points_by_bits[c][n]
+                pad = 2 ** (N - 1) - 1 if n == 0 else 2 ** (N - 1) - 2 ** (n - 1)
+                grids[c, n] = np.pad(np.array([lvl[0]] * 2) if n == 0 else lvl, (pad,), "edge")
+        self._search_grids = grids
+        # The kernels need the merged table to be non-decreasing in xi (then rank order == sorted order).
+        from .tables import rank_of_slot
+        in_rank_order = np.empty_like(self.all_code_points)
+        in_rank_order[:, rank_of_slot(N)] = self.all_code_points
+        if not np.all(np.diff(in_rank_order, axis=1) >= 0):
+            raise ValueError("prior.inverse_cdf is not monotone in xi after the float32 cast; the reference's "
+                             "per-level searchsorted (quantizer.py:74) is undefined on such tables")
+        self._strict = bool(np.all(np.diff(in_rank_order, axis=1) > 0))
+        # canonical index of quantizer.py:135/223: first sorted position holding the same value
+        self._canon = (np.stack([np.searchsorted(r, r, side="left") for r in in_rank_order]).astype(np.int64)
+                       if not self._strict else None)
+        self._dev_cache = {}
+
+    def _table_dev(self):
+        return self._dev("table_lm", lambda: torch.from_numpy(self.all_code_points))
+
+    def _sorted_dev(self):
+        return self._dev("sorted", lambda: torch.from_numpy(self.code_points_by_channel))
+
+    # ------------------------------------------------------------------ compat helper (quantizer.py:65-80)
+    def get_all_N_bit_intervals(self, Z):
+        """Left/right n-bit neighbours, C x (N+1) x B.  Kept for API compatibility only: the
+        solve below never materialises these tensors."""
+        Zt = torch.as_tensor(_to_numpy(Z) if not isinstance(Z, torch.Tensor) else Z, dtype=torch.float32).to(self.device)
+        grids = self._dev("grids", lambda: torch.from_numpy(self._search_grids))
+        G = grids.shape[-1]
+        zr = Zt.t().contiguous()[:, None, :].expand(-1, grids.shape[1], -1).contiguous()
+        r = torch.searchsorted(grids, zr, right=False).clamp_(0, G - 1)
+        l = (r - 1).clamp_(0, G - 1)
+        return torch.gather(grids, 2, l), torch.gather(grids, 2, r)
+
+    # ------------------------------------------------------------------ the solve
+    def _prep(self, batch_means, batch_stds):
+        mu = torch.as_tensor(_to_numpy(batch_means) if not isinstance(batch_means, torch.Tensor) else batch_means)
+        sg = torch.as_tensor(_to_numpy(batch_stds) if not isinstance(batch_stds, torch.Tensor) else batch_stds)
+        mu = mu.to(self.device, torch.float32)
+        sg = sg.to(self.device, torch.float32)
+        if mu.dim() != 2 or mu.shape[1] != self.num_channels or mu.shape != sg.shape:
+            raise ValueError(f"expected means/stds of shape [B, {self.num_channels}], got {tuple(mu.shape)} / {tuple(sg.shape)}")
+        # channel-major planes [C, B]
+        return mu.t().contiguous(), sg.t().contiguous()
+
+    def _level_len_dev(self, lambs) -> Optional[torch.Tensor]:
+        """quantizer.py:166,171-175: None for raw lengths, else f32 [L, C, N+1] = n + overhead."""
+        if not self.raw_code_length_entropy_models:
+            return None
+        N = self.max_bits_per_coord
+        lv = np.arange(N + 1, dtype=np.int32).astype(np.float32)
+        rows = []
+        for lamb in lambs:
+            model = np.asarray(self.raw_code_length_entropy_models[lamb])            # C x (N+1), KeyError as in the reference
+            rows.append(lv[None, :].astype(model.dtype) + model)
+        return torch.from_numpy(np.stack(rows).astype(np.float32)).to(self.device)
+
+    def _solve_idx(self, mu_cb, sg_cb, lambs, level_len):
+        """u16 rank indices [L, C, B] on the device."""
+        return ops.quantize(mu_cb, sg_cb, self._table_dev(), [float(l) for l in lambs], N=self.max_bits_per_coord,
+                            level_len=level_len, layout="cb")
+
+    def _rank_levels_dev(self):
+        return self._dev("rank_levels", lambda: torch.from_numpy(_entropy.rank_levels(self.max_bits_per_coord)))
+
+    def compress_batch_channel_latents(self, batch_means, batch_stds, lambs, return_np=True, **kwargs):
+        """quantizer.py:156-188 -> (Z_hat_dict, num_bits_dict), each dict[lamb] -> [B, C].
+        num_bits is int32 (raw bit lengths) before the raw-length entropy models exist and
+        float32 (n + overhead) afterwards, as in the reference."""
+        lambs = list(lambs)
+        N, C = self.max_bits_per_coord, self.num_channels
+        mu_cb, sg_cb = self._prep(batch_means, batch_stds)
+        level_len = self._level_len_dev(lambs)
+        idx = self._solve_idx(mu_cb, sg_cb, lambs, level_len)                        # [L, C, B]
+        zhat = ops.gather(idx, self._sorted_dev(), C, N=N, layout="cb")              # [L, C, B] f32
+        lev = self._rank_levels_dev()
+        if level_len is None:
+            bits = lev[idx.to(torch.int64)].to(torch.int32)
+        else:
+            tab = torch.gather(level_len, 2, lev.expand(len(lambs), C, -1))          # [L, C, T]: length of every rank
+            bits = ops.gather(idx, tab.contiguous(), C, N=N, layout="cb")
+        Z_hat_dict, num_bits_dict = {}, {}
+        for i, lamb in enumerate(lambs):
+            z, b = zhat[i].t().contiguous(), bits[i].t().contiguous()               # B x C
+            Z_hat_dict[lamb] = z.cpu().numpy() if return_np else z
+            num_bits_dict[lamb] = b.cpu().numpy() if return_np else b
+        return Z_hat_dict, num_bits_dict
+
+    # ------------------------------------------------------------------ entropy models (quantizer.py:82-150)
+    def _counts(self, idx) -> torch.Tensor:
+        cnt = ops.histogram(idx, self.num_channels, N=self.max_bits_per_coord, layout="cb")   # int64 [L, C, T]
+        if self.process_group is not None:
+            import torch.distributed as dist
+            dist.all_reduce(cnt, op=dist.ReduceOp.SUM, group=self.process_group)
+        return cnt
+
+    def _encode(self, X, vae):
+        posterior_means, posterior_logvars = vae.encode(X)
+        m = posterior_means if isinstance(posterior_means, torch.Tensor) else torch.from_numpy(_to_numpy(posterior_means))
+        lv = posterior_logvars if isinstance(posterior_logvars, torch.Tensor) else torch.from_numpy(_to_numpy(posterior_logvars))
+        return m.to(self.device, torch.float32), lv.to(self.device, torch.float32)
+
+    def _flatten(self, means, logvars):
+        C = logvars.shape[-1]
+        assert C == self.num_channels                                               # quantizer.py:89,195
+        batch_means = means.reshape(-1, C)
+        batch_stds = torch.exp(logvars).reshape(-1, C) ** 0.5                        # quantizer.py:87,92
+        return batch_means, batch_stds
+
+    def build_entropy_models(self, X, vae, lambs, add_n_smoothing):
+        means, logvars = self._encode(X, vae)
+        return self.build_entropy_models_from_latents(*self._flatten(means, logvars), lambs, add_n_smoothing)
+
+    def build_entropy_models_from_latents(self, batch_means, batch_stds, lambs, add_n_smoothing):
+        """The body of quantizer.py:94-150 on (B x C) means/stds."""
+        lambs = list(lambs)
+        N = self.max_bits_per_coord
+        mu_cb, sg_cb = self._prep(batch_means, batch_stds)
+        self.raw_code_length_entropy_models = None
+        # pass 1: raw bit lengths -> per-channel histogram of the number of bits (:96-112)
+        idx1 = self._solve_idx(mu_cb, sg_cb, lambs, None)
+        lvl_counts = _entropy.level_counts_from_counts(self._counts(idx1), N)        # [L, C, N+1]
+        raw_models = _entropy.neg_log2_freq(lvl_counts, add_n_smoothing)
+        self.raw_code_length_entropy_models = {lamb: raw_models[i] for i, lamb in enumerate(lambs)}
+        # pass 2: corrected lengths -> per-channel histogram of the code points (:118-148)
+        idx2 = self._solve_idx(mu_cb, sg_cb, lambs, self._level_len_dev(lambs))
+        counts = self._counts(idx2).cpu().numpy()
+        if not self._strict:       # qidx is the FIRST sorted position of a repeated value (:135)
+            merged = np.zeros_like(counts)
+            for c in range(self.num_channels):
+                np.add.at(merged[:, c, :], (slice(None), self._canon[c]), counts[:, c, :])
+            counts = merged
+        models = _entropy.neg_log2_freq(counts, add_n_smoothing)                    # [L, C, T] f32
+        self.entropy_models = {lamb: models[i] for i, lamb in enumerate(lambs)}
+        self._dev_cache.pop("entropy", None)
+        return None
+
+    @property
+    def lambs(self):
+        return list(sorted(self.entropy_models.keys()))
+
+    # ------------------------------------------------------------------ compression (quantizer.py:190-256)
+    def compress_latents(self, posterior_means, posterior_logvars, lambs):
+        lambs = list(lambs)
+        N, C = self.max_bits_per_coord, self.num_channels
+        shape = tuple(np.shape(posterior_means))
+        m = posterior_means if isinstance(posterior_means, torch.Tensor) else torch.from_numpy(_to_numpy(posterior_means))
+        lv = posterior_logvars if isinstance(posterior_logvars, torch.Tensor) else torch.from_numpy(_to_numpy(posterior_logvars))
+        batch_means, batch_stds = self._flatten(m.to(self.device, torch.float32), lv.to(self.device, torch.float32))
+        mu_cb, sg_cb = self._prep(batch_means, batch_stds)
+        level_len = self._level_len_dev(lambs)
+        idx = self._solve_idx(mu_cb, sg_cb, lambs, level_len)                        # [L, C, B]
+        zhat = ops.gather(idx, self._sorted_dev(), C, N=N, layout="cb")
+        lev = self._rank_levels_dev()
+        if level_len is None:
+            raw_bits = lev[idx.to(torch.int64)].to(torch.int32)
+        else:
+            tab = torch.gather(level_len, 2, lev.expand(len(lambs), C, -1)).contiguous()
+            raw_bits = ops.gather(idx, tab, C, N=N, layout="cb")
+        models = np.stack([np.asarray(self.entropy_models[lamb]) for lamb in lambs]).astype(np.float32)   # [L, C, T]
+        if not self._strict:       # the reference indexes with the canonical qidx; same value either way once
+            models = np.stack([np.take_along_axis(mm, self._canon, axis=1) for mm in models])            # mapped per rank
+        num_bits = ops.gather(idx, torch.from_numpy(models).to(self.device), C, N=N, layout="cb")       # :226-228
+        out_keys = ("Z_hat", "raw_num_bits", "num_bits_cl", "num_bits")
+        output = {key: dict() for key in out_keys}
+        for i, lamb in enumerate(lambs):
+            def to_latent_shape(t):
+                return t.t().contiguous().cpu().numpy().reshape(shape)              # B x C -> latent shape (:237)
+            output["Z_hat"][lamb] = to_latent_shape(zhat[i])
+            output["raw_num_bits"][lamb] = to_latent_shape(raw_bits[i])
+            if self.raw_code_length_entropy_models:
+                output["num_bits_cl"][lamb] = output["raw_num_bits"][lamb]          # :231-232
+            output["num_bits"][lamb] = to_latent_shape(num_bits[i])
+        return output
+
+    def compress(self, X, vae, lambs, clip=True):
+        lambs = list(lambs)
+        posterior_means, posterior_logvars = vae.encode(X)
+        output = self.compress_latents(posterior_means, posterior_logvars, lambs)
+        Z_hat_dict = output["Z_hat"]
+        Z_hat_batch = np.stack([Z_hat_dict[lamb] for lamb in lambs])                 # len(lambs) x latent shape
+        latent_shape = tuple(np.shape(posterior_means))
+        Z_flat = Z_hat_batch.reshape((-1,) + latent_shape[1:])
+        if isinstance(posterior_means, torch.Tensor):
+            Z_flat = torch.from_numpy(Z_flat).to(posterior_means.device)
+        X_hat_batch = _to_numpy(vae.decode(Z_flat)).reshape((len(lambs),) + tuple(np.shape(X)))
+        if clip:
+            X_hat_batch = np.clip(X_hat_batch, 0, 1)
+        output["X_hat"] = {lamb: X_hat_batch[i] for i, lamb in enumerate(lambs)}
+        return output
