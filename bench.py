@@ -113,8 +113,19 @@ def main():
     mu_h, sg_h, tab_h = make_inputs(rows, C, seed=1000 + rank)
     mu, sg, tab = torch.from_numpy(mu_h).to(dev), torch.from_numpy(sg_h).to(dev), torch.from_numpy(tab_h).to(dev)
     E = rows * C
-    shape = (rows, C) if C > 1 else (rows,)
-    mu, sg = mu.reshape(shape), sg.reshape(shape)
+    # Channel-last [rows, C] is how the latents arrive (quantizer.py:90-91).  The kernels work on
+    # channel-major planes [C, rows]; the layout change is part of every timed step.
+    if C > 1:
+        mu_in, sg_in = mu.reshape(rows, C), sg.reshape(rows, C)
+        mu = torch.empty((C, rows), dtype=torch.float32, device=dev)
+        sg = torch.empty((C, rows), dtype=torch.float32, device=dev)
+        ops.transpose(mu_in, out=mu)
+        ops.transpose(sg_in, out=sg)
+        shape, layout = (C, rows), "cb"
+    else:
+        mu_in = sg_in = None
+        mu, sg = mu.reshape(rows), sg.reshape(rows)
+        shape, layout = (rows,), "bc"
     idx = torch.empty((L,) + shape, dtype=torch.uint16, device=dev)
     counts = torch.zeros((L, C, T), dtype=torch.int64, device=dev)
     ws = torch.empty(ops._lib.lib().vbq_quantize_workspace_bytes(C, L, N_BITS), dtype=torch.uint8, device=dev)
@@ -123,8 +134,8 @@ def main():
     level_len = None
     if not args.raw_lengths:
         from vbq_amd.entropy import level_lengths_from_counts
-        ops.quantize(mu, sg, tab, LAMBDAS, N=N_BITS, out_idx=idx, workspace=ws)
-        c1 = ops.histogram(idx, C, N=N_BITS)
+        ops.quantize(mu, sg, tab, LAMBDAS, N=N_BITS, layout=layout, out_idx=idx, workspace=ws)
+        c1 = ops.histogram(idx, C, N=N_BITS, layout=layout)
         if world > 1:
             dist.all_reduce(c1)
         level_len = level_lengths_from_counts(c1, N_BITS, add_n_smoothing=1)          # f32 [L, C, N+1] on device
@@ -133,16 +144,19 @@ def main():
     evh = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
     def step(i=None):
+        if mu_in is not None:
+            ops.transpose(mu_in, out=mu)
+            ops.transpose(sg_in, out=sg)
         if i is not None:
             ev[i][0].record()
-        ops.quantize(mu, sg, tab, LAMBDAS, N=N_BITS, level_len=level_len, out_idx=idx, workspace=ws)
+        ops.quantize(mu, sg, tab, LAMBDAS, N=N_BITS, level_len=level_len, layout=layout, out_idx=idx, workspace=ws)
         if i is not None:
             ev[i][1].record()
         if args.stage == "full":
             counts.zero_()
             if i is not None:
                 evh[i][0].record()
-            ops.histogram(idx, C, N=N_BITS, out=counts)
+            ops.histogram(idx, C, N=N_BITS, layout=layout, out=counts)
             if i is not None:
                 evh[i][1].record()
             if world > 1:
@@ -190,9 +204,9 @@ def main():
             "config": {"workload": f"{args.workload}: {desc}; {L}-point lambda sweep 2**linspace(-8,7.5,32); "
                                    f"N={N_BITS} (2047 code points/channel); "
                                    f"{'raw' if args.raw_lengths else 'corrected'} code lengths; stage={args.stage} "
-                                   f"(K1 solve{' + K2 histogram' + (' + RCCL all-reduce' if world > 1 else '') if args.stage == 'full' else ''})",
+                                   f"({'layout change + ' if C > 1 else ''}K1 solve{' + K2 histogram' + (' + RCCL all-reduce' if world > 1 else '') if args.stage == 'full' else ''})",
                        "elements_per_gpu": E, "lambdas": L, "parallelism": f"element-sharded x{world}"},
-            "roofline": {"bound": "hbm", "kernel": "k_quant_tiled" if C > 1 else "k_quant_flat",
+            "roofline": {"bound": "hbm", "kernel": "k_quant_fast",
                          "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": None,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": k1_ms,
@@ -204,7 +218,7 @@ def main():
         cb, idx_cpu, n = cpu_baseline(mu_h, sg_h, tab_h, ll_h)
         out["cpu_baseline"] = cb
         # the sample doubles as an in-run parity check of the timed configuration
-        got = idx[:, :n].cpu().numpy().reshape(idx_cpu.shape)
+        got = (idx[:, :, :n].permute(0, 2, 1) if C > 1 else idx[:, :n]).cpu().numpy().reshape(idx_cpu.shape)
         out["parity_vs_oracle_on_sample"] = bool(np.array_equal(got, idx_cpu))
     elif rank == 0:
         out["cpu_baseline"] = None

@@ -158,10 +158,20 @@ int vbq_moments_f32(const float *d_x, int64_t n_rows, int32_t n_ch, int32_t layo
  *   tf.gather(code_points_by_channel, qidx, batch_dims=1) quantizer.py:136
  *   d_tab   f32 [n_lambda][n_ch][T] when tab_per_lambda != 0, else [n_ch][T];
  *           indexed by rank (i.e. a SORTED table such as code_points_by_channel).
+ *   layout / out_layout: element layout of d_idx and of d_out (they may differ: the
+ *           Z_hat / num_bits handed back to the caller are channel-last, :228,237).
  * ---------------------------------------------------------------------------------- */
 int vbq_gather_f32(const uint16_t *d_idx, int64_t n_rows, int32_t n_ch, int32_t layout,
                    int32_t n_lambda, int32_t N, const float *d_tab, int32_t tab_per_lambda,
-                   float *d_out, void *stream);
+                   float *d_out, int32_t out_layout, void *stream);
+
+/* ----------------------------------------------------------------------------------
+ * Layout change between channel-last and channel-major planes: out[c][r] = in[r][c]
+ * (f32, LDS-tiled).  Replaces the tf.transpose calls around the solve
+ * (quantizer.py:73,163-164,223,228): the hot kernels want [C][B] planes so that a
+ * workgroup works on ONE channel (one 8 KB table in LDS, wave-uniform penalties).
+ * ---------------------------------------------------------------------------------- */
+int vbq_transpose_f32(const float *d_in, int64_t n_rows, int64_t n_cols, float *d_out, void *stream);
 
 /* ----------------------------------------------------------------------------------
  * K4  BMSHJ2018 prior (learned_prior.py).  Parameters are the EFFECTIVE ones --

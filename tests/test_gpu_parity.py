@@ -228,6 +228,17 @@ def test_gather_vs_numpy(ops, rows, C):
         assert np.array_equal(g2[l], tab[0][cc, ii[l]])
     g3 = host(ops.gather(dev(idx.transpose(0, 2, 1)), dev(tab), C, N=N, layout="cb"))
     assert np.array_equal(g3.transpose(0, 2, 1), g)
+    # layout-changing form: channel-major indices in, channel-last values out (and back)
+    g4 = host(ops.gather(dev(idx.transpose(0, 2, 1)), dev(tab), C, N=N, layout="cb", out_layout="bc"))
+    assert g4.shape == g.shape and np.array_equal(g4, g)
+    g5 = host(ops.gather(dev(idx), dev(tab[0]), C, N=N, layout="bc", out_layout="cb"))
+    assert np.array_equal(g5.transpose(0, 2, 1), g2)
+
+
+@pytest.mark.parametrize("rows,cols", [(1, 1), (64, 64), (100, 37), (36864, 32), (1000, 257)])
+def test_transpose(ops, rows, cols):
+    x = np.random.default_rng(rows).normal(size=(rows, cols)).astype(np.float32)
+    assert np.array_equal(host(ops.transpose(dev(x))), x.T)
 
 
 def test_bmshj_vs_oracle(ops):

@@ -32,7 +32,8 @@ SIGNATURES = {
                                     C.c_void_p]),
     "vbq_moments_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "vbq_gather_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
-                                 C.c_int32, C.c_void_p, C.c_void_p]),
+                                 C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
+    "vbq_transpose_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
     "vbq_argmax_candidates_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64,
                                             C.POINTER(C.c_double), C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                             C.c_void_p, C.c_void_p, C.c_void_p]),

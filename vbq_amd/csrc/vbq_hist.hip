@@ -5,12 +5,60 @@
 // (u32), streams its share of the u16 indices with 16-B loads, and flushes the non-zero
 // bins with one 64-bit global atomic each.  Integer adds: the result does not depend on
 // the order of arrival, the grid shape or the number of GPUs.
+#include <stdlib.h>
+
 #include "vbq_common.h"
 
 namespace vbq {
 namespace {
 
 constexpr int kHistThreads = 256;
+
+// LDS slot of rank index q.  In rank order every code point of bit levels 0..5 sits at
+// q = 31 (mod 32) -- one LDS bank -- and those are exactly the bins that fill up at large
+// lambda.  q ^ (q >> 6) is a bijection of [0, 2^11) that spreads every level evenly over the
+// 32 banks (measured: the histogram pass went from 0.65 ms to the load-bound time).
+__device__ __forceinline__ unsigned int bin_slot(unsigned int q) { return q ^ (q >> 6); }
+
+// Eight indices of one thread (one 16-B load) into the LDS histogram.
+// An LDS atomic wave-instruction costs ~3 cycles per lane that shares a bank with another
+// lane (same address included, unless ALL lanes agree), and at large lambda 50-90 % of the
+// indices are one and the same bin.  So: (1) the thread counts how many of its eight indices
+// equal its first one and issues the other seven adds only where they differ (few active
+// lanes); (2) the lanes whose first index equals the wave leader's are summed with four
+// ballots and added by one lane.  Spread-out distributions pay ~10 extra VALU ops per index.
+__device__ __forceinline__ void hist_add8(unsigned int *h, const uint4 v) {
+    unsigned int s[8];
+    {
+        const unsigned int w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            s[2 * k] = bin_slot(w[k] & 0xffffu);
+            s[2 * k + 1] = bin_slot(w[k] >> 16);
+        }
+    }
+    unsigned int cnt = 1;
+    bool eq[8];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) {
+        eq[k] = s[k] == s[0];
+        cnt += eq[k] ? 1u : 0u;
+    }
+    const unsigned int lead = __builtin_amdgcn_readfirstlane(s[0]);
+    const bool same = s[0] == lead;
+    unsigned int tot = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+        tot += (unsigned int)__popcll(__ballot(same && ((cnt >> b) & 1u))) << b;
+    const unsigned long long same_mask = __ballot(same);
+    const int first = __ffsll((long long)same_mask) - 1;
+    const int lane = threadIdx.x & 63;
+    if (lane == first) atomicAdd(&h[lead], tot);
+    if (!same) atomicAdd(&h[s[0]], cnt);
+#pragma unroll
+    for (int k = 1; k < 8; ++k)
+        if (!eq[k]) atomicAdd(&h[s[k]], 1u);
+}
 
 // All indices of the workgroup belong to one channel: [l][c][n_per_ch] contiguous.
 template <int N>
@@ -24,22 +72,31 @@ k_hist_flat(const uint16_t *__restrict__ idx, long n_per_ch, int C, long E,
     __syncthreads();
     const uint16_t *src = idx + (long)l * E + (long)c * n_per_ch;
     const long noct = vec_ok ? (n_per_ch >> 3) : 0;
-    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < noct; q += (long)gridDim.x * blockDim.x) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    // iterations in which every lane of the wave has two full loads take the aggregated path
+    const int lane = threadIdx.x & 63;
+    for (; (q - lane) + 63 + stride < noct; q += 2 * stride) {
+        const uint4 v0 = *reinterpret_cast<const uint4 *>(src + q * 8);
+        const uint4 v1 = *reinterpret_cast<const uint4 *>(src + (q + stride) * 8);
+        hist_add8(h, v0);
+        hist_add8(h, v1);
+    }
+    for (; q < noct; q += stride) {
         const uint4 v = *reinterpret_cast<const uint4 *>(src + q * 8);
         const unsigned int w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            atomicAdd(&h[w[k] & 0xffffu], 1u);
-            atomicAdd(&h[w[k] >> 16], 1u);
+            atomicAdd(&h[bin_slot(w[k] & 0xffffu)], 1u);
+            atomicAdd(&h[bin_slot(w[k] >> 16)], 1u);
         }
     }
-    for (long i = noct * 8 + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n_per_ch;
-         i += (long)gridDim.x * blockDim.x)
-        atomicAdd(&h[src[i]], 1u);
+    for (long i = noct * 8 + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n_per_ch; i += stride)
+        atomicAdd(&h[bin_slot(src[i])], 1u);
     __syncthreads();
     unsigned long long *dst = counts + ((long)l * C + c) * T;
     for (int i = threadIdx.x; i < T; i += blockDim.x) {
-        const unsigned int v = h[i];
+        const unsigned int v = h[bin_slot(i)];
         if (v) atomicAdd(&dst[i], (unsigned long long)v);
     }
 }
@@ -63,12 +120,12 @@ k_hist_tiled(const uint16_t *__restrict__ idx, long n_rows, int C, long E,
     const uint16_t *src = idx + (long)l * E;
     if (cl < ncg) {
         for (long r = (long)blockIdx.x * 64 + slot; r < n_rows; r += (long)gridDim.x * 64)
-            atomicAdd(&hs[cl * TS + src[r * C + c0 + cl]], 1u);
+            atomicAdd(&hs[cl * TS + bin_slot(src[r * C + c0 + cl])], 1u);
     }
     __syncthreads();
     for (int i = threadIdx.x; i < ncg * T; i += blockDim.x) {
         const int ch = i / T, s = i - ch * T;
-        const unsigned int v = hs[ch * TS + s];
+        const unsigned int v = hs[ch * TS + bin_slot(s)];
         if (v) atomicAdd(&counts[((long)l * C + c0 + ch) * T + s], (unsigned long long)v);
     }
 }
@@ -180,6 +237,7 @@ k_moments_bc(const float *__restrict__ x, long n_rows, int C, double *__restrict
 }
 
 // ---------------------------------------------------------------------------- gather
+// same layout in and out: one coalesced pass
 __global__ void __launch_bounds__(256)
 k_gather(const uint16_t *__restrict__ idx, long n_rows, int C, int layout, long E, int T,
          const float *__restrict__ tab, int per_lambda, float *__restrict__ out) {
@@ -190,6 +248,52 @@ k_gather(const uint16_t *__restrict__ idx, long n_rows, int C, int layout, long 
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (long)gridDim.x * blockDim.x) {
         const int c = (C == 1) ? 0 : (layout == VBQ_LAYOUT_BC ? (int)(e % C) : (int)(e / n_rows));
         dst[e] = tl[(long)c * T + src[e]];
+    }
+}
+
+// idx and out in different layouts: 32 x 32 tiles through LDS, both sides coalesced.
+// in_rows x in_cols is the shape of the idx matrix as stored ([C][B] for CB, [B][C] for BC).
+__global__ void __launch_bounds__(256)
+k_gather_transpose(const uint16_t *__restrict__ idx, long in_rows, long in_cols, int in_layout, long E, int C, int T,
+                   const float *__restrict__ tab, int per_lambda, float *__restrict__ out) {
+    __shared__ float tile[32][33];
+    const int l = blockIdx.z;
+    const uint16_t *src = idx + (long)l * E;
+    float *dst = out + (long)l * E;
+    const float *tl = tab + (per_lambda ? (long)l * C * T : 0);
+    const long r0 = (long)blockIdx.y * 32, c0 = (long)blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const long r = r0 + ty + 8 * k, c = c0 + tx;
+        if (r < in_rows && c < in_cols) {
+            const int ch = in_layout == VBQ_LAYOUT_CB ? (int)r : (int)c;
+            tile[ty + 8 * k][tx] = tl[(long)ch * T + src[r * in_cols + c]];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const long c = c0 + ty + 8 * k, r = r0 + tx;                 // output row = input column
+        if (r < in_rows && c < in_cols) dst[c * in_rows + r] = tile[tx][ty + 8 * k];
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_transpose(const float *__restrict__ in, long rows, long cols, float *__restrict__ out) {
+    __shared__ float tile[64][65];
+    const long r0 = (long)blockIdx.y * 64, c0 = (long)blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;          // 64 x 4
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const long r = r0 + ty + 4 * k, c = c0 + tx;
+        if (r < rows && c < cols) tile[ty + 4 * k][tx] = in[r * cols + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const long c = c0 + ty + 4 * k, r = r0 + tx;
+        if (r < rows && c < cols) out[c * rows + r] = tile[tx][ty + 4 * k];
     }
 }
 
@@ -252,15 +356,28 @@ extern "C" int vbq_moments_f32(const float *d_x, int64_t n_rows, int32_t n_ch, i
 
 extern "C" int vbq_gather_f32(const uint16_t *d_idx, int64_t n_rows, int32_t n_ch, int32_t layout,
                               int32_t n_lambda, int32_t N, const float *d_tab, int32_t tab_per_lambda,
-                              float *d_out, void *stream) {
+                              float *d_out, int32_t out_layout, void *stream) {
     using namespace vbq;
     VBQ_REQUIRE(n_rows == 0 || (d_idx && d_tab && d_out), VBQ_ERR_INVALID_ARGUMENT, "vbq_gather_f32: null pointer argument");
     VBQ_REQUIRE(n_rows >= 0 && n_ch >= 1 && n_lambda >= 1 && n_lambda <= 65535 && N >= 0 && N <= 15,
                 VBQ_ERR_INVALID_ARGUMENT, "vbq_gather_f32: bad sizes");
-    VBQ_REQUIRE(layout == VBQ_LAYOUT_BC || layout == VBQ_LAYOUT_CB, VBQ_ERR_INVALID_ARGUMENT,
-                "vbq_gather_f32: unknown layout %d", layout);
+    VBQ_REQUIRE((layout == VBQ_LAYOUT_BC || layout == VBQ_LAYOUT_CB) &&
+                    (out_layout == VBQ_LAYOUT_BC || out_layout == VBQ_LAYOUT_CB),
+                VBQ_ERR_INVALID_ARGUMENT, "vbq_gather_f32: unknown layout %d -> %d", layout, out_layout);
     if (n_rows == 0) return VBQ_OK;
     const int64_t E = n_rows * (int64_t)n_ch;
+    if (n_ch > 1 && layout != out_layout) {
+        const int64_t in_rows = layout == VBQ_LAYOUT_CB ? n_ch : n_rows;
+        const int64_t in_cols = layout == VBQ_LAYOUT_CB ? n_rows : n_ch;
+        VBQ_REQUIRE(n_lambda <= 65535 && (in_rows + 31) / 32 <= 65535, VBQ_ERR_UNSUPPORTED,
+                    "vbq_gather_f32: grid too large for the transposing form");
+        hipLaunchKernelGGL(k_gather_transpose, dim3((unsigned)((in_cols + 31) / 32), (unsigned)((in_rows + 31) / 32),
+                                                    (unsigned)n_lambda),
+                           dim3(256), 0, reinterpret_cast<hipStream_t>(stream), d_idx, (long)in_rows, (long)in_cols,
+                           (int)layout, (long)E, (int)n_ch, table_size(N), d_tab, (int)tab_per_lambda, d_out);
+        VBQ_CHECK_LAUNCH("gather_transpose");
+        return VBQ_OK;
+    }
     int64_t gx = (E + 255) / 256;
     const int64_t cap = 4096 / n_lambda + 1;
     if (gx > cap) gx = cap;
@@ -268,5 +385,17 @@ extern "C" int vbq_gather_f32(const uint16_t *d_idx, int64_t n_rows, int32_t n_c
                        reinterpret_cast<hipStream_t>(stream), d_idx, (long)n_rows, (int)n_ch, (int)layout, (long)E,
                        table_size(N), d_tab, (int)tab_per_lambda, d_out);
     VBQ_CHECK_LAUNCH("gather");
+    return VBQ_OK;
+}
+
+extern "C" int vbq_transpose_f32(const float *d_in, int64_t n_rows, int64_t n_cols, float *d_out, void *stream) {
+    using namespace vbq;
+    VBQ_REQUIRE(n_rows >= 0 && n_cols >= 0, VBQ_ERR_INVALID_ARGUMENT, "vbq_transpose_f32: bad sizes");
+    if (n_rows == 0 || n_cols == 0) return VBQ_OK;
+    VBQ_REQUIRE(d_in && d_out && d_in != d_out, VBQ_ERR_INVALID_ARGUMENT, "vbq_transpose_f32: null or aliased pointers");
+    VBQ_REQUIRE((n_rows + 63) / 64 <= 65535, VBQ_ERR_UNSUPPORTED, "vbq_transpose_f32: more than 4.19e6 rows");
+    hipLaunchKernelGGL(k_transpose, dim3((unsigned)((n_cols + 63) / 64), (unsigned)((n_rows + 63) / 64)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), d_in, (long)n_rows, (long)n_cols, d_out);
+    VBQ_CHECK_LAUNCH("transpose");
     return VBQ_OK;
 }

@@ -162,9 +162,11 @@ def moments(x: torch.Tensor, *, layout="bc", out: Optional[torch.Tensor] = None)
     return out
 
 
-def gather(idx: torch.Tensor, tab: torch.Tensor, n_ch: int, *, N: int = 10, layout="bc"):
-    """vbq_gather_f32: out[l][e] = tab[(l,) c(e), idx[l][e]].  tab: f32 [C, T] or [L, C, T] indexed by RANK."""
+def gather(idx: torch.Tensor, tab: torch.Tensor, n_ch: int, *, N: int = 10, layout="bc", out_layout=None):
+    """vbq_gather_f32: out[l][e] = tab[(l,) c(e), idx[l][e]].  tab: f32 [C, T] or [L, C, T] indexed by RANK.
+    With out_layout != layout the result comes back transposed (e.g. idx [L, C, B] -> out [L, B, C])."""
     layout = _LAYOUTS[layout]
+    out_layout = layout if out_layout is None else _LAYOUTS[out_layout]
     idx = _dev(idx, torch.uint16, "idx")
     tab = _dev(tab, torch.float32, "tab")
     L = idx.shape[0]
@@ -174,9 +176,30 @@ def gather(idx: torch.Tensor, tab: torch.Tensor, n_ch: int, *, N: int = 10, layo
     per_lambda = tab.dim() == 3
     if tuple(tab.shape) != ((L, n_ch, T) if per_lambda else (n_ch, T)):
         raise ValueError(f"tab shape {tuple(tab.shape)} does not match (L={L}, C={n_ch}, T={T})")
-    out = torch.empty(idx.shape, dtype=torch.float32, device=idx.device)
+    oshape = tuple(idx.shape)
+    if out_layout != layout and idx.dim() == 3 and n_ch == 1:
+        oshape = (L, idx.shape[2], idx.shape[1])          # same memory, other view
+    if out_layout != layout and n_ch > 1:
+        if idx.dim() != 3:
+            raise ValueError("a layout change needs idx of shape [L, rows, C] or [L, C, rows]")
+        oshape = (L, idx.shape[2], idx.shape[1])
+    out = torch.empty(oshape, dtype=torch.float32, device=idx.device)
     check(_lib.lib().vbq_gather_f32(_ptr(idx), rows, n_ch, layout, L, N, _ptr(tab), int(per_lambda), _ptr(out),
-                                    _stream(idx)), "vbq_gather_f32")
+                                    out_layout, _stream(idx)), "vbq_gather_f32")
+    return out
+
+
+def transpose(x: torch.Tensor, out: Optional[torch.Tensor] = None):
+    """vbq_transpose_f32: [rows, cols] f32 -> [cols, rows] (channel-last <-> channel-major planes)."""
+    x = _dev(x, torch.float32, "x")
+    if x.dim() != 2:
+        raise ValueError("transpose expects a 2-D tensor")
+    r, c = x.shape
+    if out is None:
+        out = torch.empty((c, r), dtype=torch.float32, device=x.device)
+    elif tuple(out.shape) != (c, r) or out.dtype != torch.float32 or not out.is_contiguous():
+        raise ValueError(f"out must be a contiguous f32 tensor of shape {(c, r)}")
+    check(_lib.lib().vbq_transpose_f32(_ptr(x), r, c, _ptr(out), _stream(x)), "vbq_transpose_f32")
     return out
 
 

@@ -145,7 +145,7 @@ class ChannelwisePriorCDFQuantizer:
         if mu.dim() != 2 or mu.shape[1] != self.num_channels or mu.shape != sg.shape:
             raise ValueError(f"expected means/stds of shape [B, {self.num_channels}], got {tuple(mu.shape)} / {tuple(sg.shape)}")
         # channel-major planes [C, B]
-        return mu.t().contiguous(), sg.t().contiguous()
+        return ops.transpose(mu.contiguous()), ops.transpose(sg.contiguous())
 
     def _level_len_dev(self, lambs) -> Optional[torch.Tensor]:
         """quantizer.py:166,171-175: None for raw lengths, else f32 [L, C, N+1] = n + overhead."""
@@ -176,16 +176,17 @@ class ChannelwisePriorCDFQuantizer:
         mu_cb, sg_cb = self._prep(batch_means, batch_stds)
         level_len = self._level_len_dev(lambs)
         idx = self._solve_idx(mu_cb, sg_cb, lambs, level_len)                        # [L, C, B]
-        zhat = ops.gather(idx, self._sorted_dev(), C, N=N, layout="cb")              # [L, C, B] f32
+        zhat = ops.gather(idx, self._sorted_dev(), C, N=N, layout="cb", out_layout="bc")   # [L, B, C] f32
         lev = self._rank_levels_dev()
         if level_len is None:
-            bits = lev[idx.to(torch.int64)].to(torch.int32)
+            tab = lev.to(torch.float32).expand(C, -1).contiguous()                   # [C, T]: level of every rank
+            bits = ops.gather(idx, tab, C, N=N, layout="cb", out_layout="bc").to(torch.int32)
         else:
             tab = torch.gather(level_len, 2, lev.expand(len(lambs), C, -1))          # [L, C, T]: length of every rank
-            bits = ops.gather(idx, tab.contiguous(), C, N=N, layout="cb")
+            bits = ops.gather(idx, tab.contiguous(), C, N=N, layout="cb", out_layout="bc")
         Z_hat_dict, num_bits_dict = {}, {}
         for i, lamb in enumerate(lambs):
-            z, b = zhat[i].t().contiguous(), bits[i].t().contiguous()               # B x C
+            z, b = zhat[i], bits[i]                                                  # B x C
             Z_hat_dict[lamb] = z.cpu().numpy() if return_np else z
             num_bits_dict[lamb] = b.cpu().numpy() if return_np else b
         return Z_hat_dict, num_bits_dict
@@ -254,22 +255,24 @@ class ChannelwisePriorCDFQuantizer:
         mu_cb, sg_cb = self._prep(batch_means, batch_stds)
         level_len = self._level_len_dev(lambs)
         idx = self._solve_idx(mu_cb, sg_cb, lambs, level_len)                        # [L, C, B]
-        zhat = ops.gather(idx, self._sorted_dev(), C, N=N, layout="cb")
+        zhat = ops.gather(idx, self._sorted_dev(), C, N=N, layout="cb", out_layout="bc")   # [L, B, C]
         lev = self._rank_levels_dev()
         if level_len is None:
-            raw_bits = lev[idx.to(torch.int64)].to(torch.int32)
+            tab = lev.to(torch.float32).expand(C, -1).contiguous()
+            raw_bits = ops.gather(idx, tab, C, N=N, layout="cb", out_layout="bc").to(torch.int32)
         else:
             tab = torch.gather(level_len, 2, lev.expand(len(lambs), C, -1)).contiguous()
-            raw_bits = ops.gather(idx, tab, C, N=N, layout="cb")
+            raw_bits = ops.gather(idx, tab, C, N=N, layout="cb", out_layout="bc")
         models = np.stack([np.asarray(self.entropy_models[lamb]) for lamb in lambs]).astype(np.float32)   # [L, C, T]
         if not self._strict:       # the reference indexes with the canonical qidx; same value either way once
             models = np.stack([np.take_along_axis(mm, self._canon, axis=1) for mm in models])            # mapped per rank
-        num_bits = ops.gather(idx, torch.from_numpy(models).to(self.device), C, N=N, layout="cb")       # :226-228
+        num_bits = ops.gather(idx, torch.from_numpy(models).to(self.device), C, N=N, layout="cb",
+                              out_layout="bc")                                                           # :226-228
         out_keys = ("Z_hat", "raw_num_bits", "num_bits_cl", "num_bits")
         output = {key: dict() for key in out_keys}
         for i, lamb in enumerate(lambs):
             def to_latent_shape(t):
-                return t.t().contiguous().cpu().numpy().reshape(shape)              # B x C -> latent shape (:237)
+                return t.cpu().numpy().reshape(shape)                               # B x C -> latent shape (:237)
             output["Z_hat"][lamb] = to_latent_shape(zhat[i])
             output["raw_num_bits"][lamb] = to_latent_shape(raw_bits[i])
             if self.raw_code_length_entropy_models:
