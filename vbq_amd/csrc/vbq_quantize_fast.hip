@@ -10,18 +10,23 @@
 //  * the two candidates of a bit level share their penalty, and rounding is monotone, so
 //    min(cost(L_n), cost(R_n)) = fl(min(dL, dR) + pen_n).  Phase A (once per element) keeps
 //    du_n = min(dL_n, dR_n) in registers (11 VGPRs) and parks one packed word per level in an
-//    LDS scratch column:  [ gap code:10 | rank of the other side:11 | rank of the better side:11 ].
-//  * phase B (per lambda): 11 adds with the wave-uniform penalties (SGPRs), a v_min3 tree for
-//    the best cost S, then sign(S - c_n) shifted into a bit mask (v_alignbit) -- two ops per
-//    level, no VCC traffic -- gives the set of levels that attain S.  One LDS read fetches the
-//    packed word of the first of them.
+//    LDS scratch column:  [ 0 | gap code:10 (float bits 30..21) | 0:10 | rank of the better side:11 ].
+//  * phase B (per lambda): 11 adds of the penalties, a v_min3 tree for the best cost S, then
+//    sign(S - c_n) shifted into a bit mask (v_alignbit) -- two ops per level, no VCC traffic --
+//    gives the set of levels that attain S.  One LDS read fetches the packed word of the first.
+//  * instruction costs measured on gfx950 (tools/ubench.hip): v_add/sub/mul_f32, and/or/xor,
+//    add/sub_u32, lshrrev run at 2 cycles per wave64; fma, min/max/min3, alignbit, cmp, cndmask,
+//    ffbl, bcnt, lshl_add and ANY op with an SGPR source run at 4.  Hence the penalties are
+//    read from an LDS copy into VGPRs (the 44 adds per lambda are then full-rate) instead of
+//    being used as SGPR operands.
 //  * exactness of the tie rules.  The reference order is [L_0..L_N, R_1..R_N], first maximum
 //    wins (utils.py:401).  Two rare events are not decided by the fast path and are flagged:
 //      (a) more than one level attains S (a cross-level tie: an L of a deeper level beats an R
 //          of a shallower one);
 //      (b) the better side of the winning level is R and the two sides are so close that
 //          fl(dL + pen) may round onto fl(dR + pen), which would hand the win to L.  The 10-bit
-//          gap code is a lower bound of |dL - dR|; the flag is raised when it is <= 2^-21 * S.
+//          gap code is a lower bound of |dL - dR| (all ones when L is the better side); the flag
+//          is raised when it is <= 2^-21 * S.
 //    A wave with any flagged lane re-solves those lanes for that lambda with the literal
 //    21-candidate scan (exact_rank_scan).  Both events have probability ~1e-6 per solve.
 #include "vbq_common.h"
@@ -37,6 +42,29 @@ __device__ __forceinline__ float dist_cost(float P, float mu, float sigma) {
     const float t = __fdiv_rn(d, sigma);
     const float q = __fmul_rn(t, t);
     return __fmul_rn(0.5f, q);
+}
+
+__device__ __forceinline__ float min3f(float a, float b, float c) { return fminf(fminf(a, b), c); }
+
+// Minimum of M values as a tree of v_min3_f32 (ceil((M-1)/2) instructions).
+template <int M>
+__device__ __forceinline__ float min_of(const float (&v)[M]) {
+    float t[M];
+#pragma unroll
+    for (int i = 0; i < M; ++i) t[i] = v[i];
+    int m = M;
+#pragma unroll
+    for (int pass = 0; pass < 8; ++pass) {
+        if (m <= 1) break;
+        int o = 0;
+        int i = 0;
+#pragma unroll
+        for (; i + 2 < m; i += 3) t[o++] = min3f(t[i], t[i + 1], t[i + 2]);
+        if (o == 0) { t[o++] = fminf(t[0], t[1]); i = 2; }      // only two values left
+        for (; i < m; ++i) t[o++] = t[i];                          // leftovers ride along to the next pass
+        m = o;
+    }
+    return t[0];
 }
 
 template <int N>
@@ -105,16 +133,20 @@ k_quant_fast(const float *__restrict__ mu, const float *__restrict__ sg, long n_
     constexpr int T = table_size(N);
     constexpr int N1 = N + 1;
     constexpr int NE = kFastNE;
+    constexpr int PS = (N1 + 3) & ~3;                 // penalty row padded to whole 16-B reads
     __shared__ float tb[T + 1];
     __shared__ uint32_t scratch[N1 * NE * kFastThreads];
+    __shared__ __align__(16) float penl[kMaxLambdaChunk * PS];
     const int c = blockIdx.y;
     for (int i = threadIdx.x; i < T; i += blockDim.x) tb[i] = table[(long)c * T + i];
+    for (int i = threadIdx.x; i < L * PS; i += blockDim.x) {
+        const int l = i / PS, n = i - l * PS;
+        penl[i] = n < N1 ? pen[((long)l * C + c) * N1 + n] : 0.0f;
+    }
     __syncthreads();
 
     const long base = (long)c * n_per_ch;
     const long nquads = (n_per_ch + NE - 1) / NE;
-    const float *pen_c = pen + (long)c * N1;
-    const long pen_stride = (long)C * N1;
 
     for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < nquads; q += (long)gridDim.x * blockDim.x) {
         const long i0 = q * NE;
@@ -149,17 +181,17 @@ k_quant_fast(const float *__restrict__ mu, const float *__restrict__ sg, long n_
                 const bool r_better = li.dR < li.dL;           // strict: on equal costs L keeps the level
                 du[k][n] = r_better ? li.dR : li.dL;
                 const uint32_t better = r_better ? rkR : rkL;
-                const uint32_t other = r_better ? rkL : rkR;
-                // lower bound of |dL - dR| in 10 bits (sign-less top bits of the float, minus one code)
-                const uint32_t gb = __float_as_uint(fabsf(__fsub_rn(li.dL, li.dR))) >> 21;
-                const uint32_t gcode = gb > 0 ? gb - 1 : 0;
-                scratch[(n * NE + k) * kFastThreads + threadIdx.x] = (gcode << 22) | (other << 11) | better;
+                // lower bound of dL - dR in 10 bits (top bits of the float, minus one code); all
+                // ones when L is the better side: then no rounding can take the level from it
+                const uint32_t gb = __float_as_uint(__fsub_rn(li.dL, li.dR)) >> 21;
+                const uint32_t gcode = r_better ? (gb > 0 ? gb - 1 : 0) : 0x3ffu;
+                scratch[(n * NE + k) * kFastThreads + threadIdx.x] = (gcode << 21) | better;
             }
         }
 
         // ---------------- phase B: one solve per lambda ----------------
         for (int l = 0; l < L; ++l) {
-            const float *pp = pen_c + (long)l * pen_stride;
+            const float *pp = penl + l * PS;
             float p[N1];
 #pragma unroll
             for (int n = 0; n < N1; ++n) p[n] = pp[n];
@@ -175,38 +207,28 @@ k_quant_fast(const float *__restrict__ mu, const float *__restrict__ sg, long n_
                 for (int k = 0; k < NE; ++k) cst[k][n] = __fadd_rn(du[k][n], p[n]);
             float S[NE];
 #pragma unroll
-            for (int k = 0; k < NE; ++k) S[k] = cst[k][0];
-#pragma unroll
-            for (int n = 1; n + 1 < N1; n += 2)
-#pragma unroll
-                for (int k = 0; k < NE; ++k) S[k] = fminf(S[k], fminf(cst[k][n], cst[k][n + 1]));
-            if ((N1 & 1) == 0) {
-#pragma unroll
-                for (int k = 0; k < NE; ++k) S[k] = fminf(S[k], cst[k][N1 - 1]);
-            }
-            uint32_t ne[NE];                                    // bit (N-n) set <=> cost_n != S
+            for (int k = 0; k < NE; ++k) S[k] = min_of<N1>(cst[k]);
+            uint32_t ne[NE];                                    // bit n set <=> cost_n != S
 #pragma unroll
             for (int k = 0; k < NE; ++k) ne[k] = 0;
 #pragma unroll
-            for (int n = 0; n < N1; ++n)
+            for (int n = N; n >= 0; --n)
 #pragma unroll
                 for (int k = 0; k < NE; ++k)
                     ne[k] = __builtin_amdgcn_alignbit(ne[k], __float_as_uint(__fsub_rn(S[k], cst[k][n])), 31);
-            uint32_t eq[NE], pk[NE];
+            uint32_t pk[NE];
 #pragma unroll
             for (int k = 0; k < NE; ++k) {
-                eq[k] = ~ne[k] & ((1u << N1) - 1u);
-                const int n1 = __clz(eq[k]) - (31 - N);         // first (shallowest) level that attains S
+                const int n1 = __builtin_ctz(~ne[k]);           // first (shallowest) level that attains S
                 pk[k] = scratch[(n1 * NE + k) * kFastThreads + threadIdx.x];
             }
 #pragma unroll
             for (int k = 0; k < NE; ++k) {
-                const uint32_t better = pk[k] & 0x7ffu, other = (pk[k] >> 11) & 0x7ffu;
-                const uint32_t gap_lo = (pk[k] >> 22) << 21;    // float bits of a lower bound of |dL-dR|
-                const bool multi = (eq[k] & (eq[k] - 1)) != 0;
-                const bool lr_close = (better > other) &&
-                                      (__uint_as_float(gap_lo) <= __fmul_rn(S[k], 4.76837158203125e-07f));
-                rank[k] = better;
+                const bool multi = __popc(ne[k]) != N;          // more than one level attains S
+                // gap code sits at the float's own bit positions [30:21]: compare bit patterns directly
+                const uint32_t thr = __float_as_uint(__fmul_rn(S[k], 4.76837158203125e-07f));
+                const bool lr_close = (pk[k] & 0x7fe00000u) <= thr;
+                rank[k] = pk[k] & 0x7ffu;
                 flagged[k] = multi || lr_close;
                 any_flag = any_flag || flagged[k];
             }
