@@ -181,6 +181,21 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    # HBM traffic of K1 per launch from the committed PMC passes (profiles/*_pmc.json): 2 x FETCH_SIZE +
+    # WRITE_SIZE, collected with rocprofv3 --pmc in separate runs of this same workload.
+    traffic, traffic_src = None, None
+    try:
+        import glob
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), reverse=True):
+            pj = json.load(open(f))
+            bl = pj.get("bench_line", {}).get("config", {})
+            if bl.get("elements_per_gpu") == rows * C and bl.get("lambdas") == L and "k_quant_fast" in pj and \
+                    bl.get("workload", "").startswith(args.workload + ":") and \
+                    "hbm_bytes_per_launch" in pj["k_quant_fast"]:
+                traffic, traffic_src = pj["k_quant_fast"]["hbm_bytes_per_launch"], os.path.relpath(f, ROOT)
+                break
+    except Exception:
+        pass
     k1_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     k2_ms = float(np.mean([a.elapsed_time(b) for a, b in evh])) if args.stage == "full" else None
     alg_bytes = E * (8 + 2 * L)
@@ -208,7 +223,7 @@ def main():
                        "elements_per_gpu": E, "lambdas": L, "parallelism": f"element-sharded x{world}"},
             "roofline": {"bound": "hbm", "kernel": "k_quant_fast",
                          "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK, "traffic": None,
+                         "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": k1_ms,
                          "latents_per_s_kernel_only": E * L / (k1_ms * 1e-3)},
             "stages_ms": {"k1_solve": k1_ms, "k2_histogram": k2_ms},
