@@ -102,11 +102,19 @@ def main():
             raise SystemExit(f"--gpus {args.gpus} needs a torch.distributed.run launch with {args.gpus} ranks")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm device")
+    # VBQ_BENCH_ONE_DEVICE=1 (+ VBQ_BENCH_BACKEND=gloo) lets the N > 1 code path be exercised on a
+    # single-GPU box: every rank uses cuda:0 and the collective runs over gloo.  Testing only.
+    if os.environ.get("VBQ_BENCH_ONE_DEVICE") == "1":
+        local = 0
+    backend = os.environ.get("VBQ_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     rows, C, desc = WORKLOADS[args.workload]
     L = len(LAMBDAS)
@@ -127,7 +135,10 @@ def main():
         mu, sg = mu.reshape(rows), sg.reshape(rows)
         shape, layout = (rows,), "bc"
     idx = torch.empty((L,) + shape, dtype=torch.uint16, device=dev)
-    counts = torch.zeros((L, C, T), dtype=torch.int64, device=dev)
+    # int32 counters halve the all-reduce payload; exact while the global rows per channel < 2^31
+    cdtype = torch.int32 if rows * world < 2 ** 31 else torch.int64
+    counts2 = [torch.zeros((L, C, T), dtype=cdtype, device=dev) for _ in range(2)]
+    works = [None, None]
     ws = torch.empty(ops._lib.lib().vbq_quantize_workspace_bytes(C, L, N_BITS), dtype=torch.uint8, device=dev)
 
     # setup (untimed): pass 1 with raw lengths -> bit-length histogram -> corrected lengths (quantizer.py:96-112)
@@ -143,7 +154,11 @@ def main():
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     evh = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
-    def step(i=None):
+    def step(i=None, slot=0):
+        counts = counts2[slot]
+        if works[slot] is not None:          # the all-reduce that last used this buffer must be done
+            works[slot].wait()
+            works[slot] = None
         if mu_in is not None:
             ops.transpose(mu_in, out=mu)
             ops.transpose(sg_in, out=sg)
@@ -160,17 +175,26 @@ def main():
             if i is not None:
                 evh[i][1].record()
             if world > 1:
-                dist.all_reduce(counts)
+                # asynchronous: the collective of step i overlaps the kernels of step i+1 (two buffers)
+                works[slot] = dist.all_reduce(counts, async_op=True)
 
-    for _ in range(args.warmup):
-        step()
+    def drain():
+        for b in range(2):
+            if works[b] is not None:
+                works[b].wait()
+                works[b] = None
+
+    for w in range(args.warmup):
+        step(None, w & 1)
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(i)
+        step(i, i & 1)
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

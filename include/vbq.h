@@ -144,6 +144,12 @@ int vbq_quantize_notebook_f64(const float *d_means, const float *d_stds, int64_t
 int vbq_histogram_u16(const uint16_t *d_idx, int64_t n_rows, int32_t n_ch, int32_t layout,
                       int32_t n_lambda, int32_t N, int64_t *d_counts, void *stream);
 
+/* Same pass with 32-bit counters: half the bytes for the cross-GPU all-reduce.  The caller
+ * guarantees that no bin can reach 2^31 -- i.e. the GLOBAL number of rows per channel (over
+ * all ranks whose histograms will be summed into this buffer) is below 2^31. */
+int vbq_histogram_u16_i32(const uint16_t *d_idx, int64_t n_rows, int32_t n_ch, int32_t layout,
+                          int32_t n_lambda, int32_t N, int32_t *d_counts, void *stream);
+
 /* ----------------------------------------------------------------------------------
  * K3  Moment pass.  Replaces empirical_std = sqrt(mean(mu^2)) (ipynb:373-374) and the
  *     per-channel mean/std a FactoredGaussianPrior needs (vae_models.py:32-35).

@@ -202,6 +202,9 @@ def test_histogram_vs_oracle(ops, rows, C):
     acc = ops.histogram(dev(idx), C, N=N)
     ops.histogram(dev(idx), C, N=N, out=acc)
     assert np.array_equal(host(acc), 2 * want)
+    # 32-bit counters (the all-reduce payload of the sharded pass)
+    c32 = ops.histogram(dev(idx), C, N=N, dtype=torch.int32)
+    assert c32.dtype == torch.int32 and np.array_equal(host(c32), want)
 
 
 @pytest.mark.parametrize("rows,C", HMG_SHAPES)

@@ -109,3 +109,21 @@ def test_utils_argument_contract():
     assert utils.n_bit_binary_floats(2) == [0.125, 0.375, 0.625, 0.875]
     with pytest.raises(TypeError):
         utils.batch_quantize_indep_dims((1, 2), np.zeros((3, 1, 2)), np.zeros((3, 1, 2)), lambda z: z, [1.0])
+
+
+def test_f64_reciprocal_division_identity():
+    """The fast kernel computes (z - mu) / sigma as RN32(RN64(d * RN64(1/sigma))) (vbq_quantize_fast.hip,
+    dist_cost).  That must be bit-identical to the IEEE f32 quotient of utils.py:320."""
+    rng = np.random.default_rng(0)
+    for _ in range(4):
+        n = 2_000_000
+        a = rng.standard_normal(n).astype(np.float32) * np.float32(10.0) ** rng.integers(-8, 8, n).astype(np.float32)
+        b = np.exp(rng.normal(-2, 2, n)).astype(np.float32)
+        pw = np.float32(2.0) ** rng.integers(-20, 20, 2000).astype(np.float32)
+        b[:1000] = np.nextafter(pw[:1000], np.float32(0))          # all-ones mantissas
+        a[1000:2000] = np.nextafter(pw[1000:], np.float32(0))
+        b[2000:3000] = pw[:1000]                                    # exact powers of two
+        a[3000:3100] = 0.0
+        q = a / b
+        q2 = (a.astype(np.float64) * (1.0 / b.astype(np.float64))).astype(np.float32)
+        assert np.array_equal(q, q2)

@@ -30,6 +30,8 @@ SIGNATURES = {
                                             C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vbq_histogram_u16": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                     C.c_void_p]),
+    "vbq_histogram_u16_i32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                        C.c_void_p, C.c_void_p]),
     "vbq_moments_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "vbq_gather_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                  C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),

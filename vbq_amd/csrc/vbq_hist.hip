@@ -61,10 +61,10 @@ __device__ __forceinline__ void hist_add8(unsigned int *h, const uint4 v) {
 }
 
 // All indices of the workgroup belong to one channel: [l][c][n_per_ch] contiguous.
-template <int N>
+template <int N, typename CountT>
 __global__ void __launch_bounds__(kHistThreads)
 k_hist_flat(const uint16_t *__restrict__ idx, long n_per_ch, int C, long E,
-            unsigned long long *__restrict__ counts, int vec_ok) {
+            CountT *__restrict__ counts, int vec_ok) {
     constexpr int T = table_size(N);
     __shared__ unsigned int h[T + 1];
     const int c = blockIdx.y, l = blockIdx.z;
@@ -94,20 +94,20 @@ k_hist_flat(const uint16_t *__restrict__ idx, long n_per_ch, int C, long E,
     for (long i = noct * 8 + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n_per_ch; i += stride)
         atomicAdd(&h[bin_slot(src[i])], 1u);
     __syncthreads();
-    unsigned long long *dst = counts + ((long)l * C + c) * T;
+    CountT *dst = counts + ((long)l * C + c) * T;
     for (int i = threadIdx.x; i < T; i += blockDim.x) {
         const unsigned int v = h[bin_slot(i)];
-        if (v) atomicAdd(&dst[i], (unsigned long long)v);
+        if (v) atomicAdd(&dst[i], (CountT)v);
     }
 }
 
 // Channel-last [rows][C], C > 1: a workgroup owns 16 consecutive channels of one lambda.
 constexpr int kHistTiledThreads = 1024;
 
-template <int N>
+template <int N, typename CountT>
 __global__ void __launch_bounds__(kHistTiledThreads)
 k_hist_tiled(const uint16_t *__restrict__ idx, long n_rows, int C, long E,
-             unsigned long long *__restrict__ counts) {
+             CountT *__restrict__ counts) {
     constexpr int T = table_size(N);
     constexpr int TS = T + 2;
     extern __shared__ unsigned int hs[];
@@ -126,13 +126,13 @@ k_hist_tiled(const uint16_t *__restrict__ idx, long n_rows, int C, long E,
     for (int i = threadIdx.x; i < ncg * T; i += blockDim.x) {
         const int ch = i / T, s = i - ch * T;
         const unsigned int v = hs[ch * TS + bin_slot(s)];
-        if (v) atomicAdd(&counts[((long)l * C + c0 + ch) * T + s], (unsigned long long)v);
+        if (v) atomicAdd(&counts[((long)l * C + c0 + ch) * T + s], (CountT)v);
     }
 }
 
-template <int N>
+template <int N, typename CountT>
 int launch_hist(const uint16_t *idx, int64_t n_rows, int32_t n_ch, int32_t layout, int32_t L,
-                unsigned long long *counts, hipStream_t st) {
+                CountT *counts, hipStream_t st) {
     const int64_t E = n_rows * (int64_t)n_ch;
     const bool flat = (n_ch == 1) || (layout == VBQ_LAYOUT_CB);
     if (flat) {
@@ -143,7 +143,7 @@ int launch_hist(const uint16_t *idx, int64_t n_rows, int32_t n_ch, int32_t layou
         int64_t cap = (int64_t)2048 / ((int64_t)n_ch * L) + 1;
         if (gx > cap) gx = cap;
         if (gx < 1) gx = 1;
-        hipLaunchKernelGGL((k_hist_flat<N>), dim3((unsigned)gx, (unsigned)n_ch, (unsigned)L), dim3(kHistThreads), 0, st,
+        hipLaunchKernelGGL((k_hist_flat<N, CountT>), dim3((unsigned)gx, (unsigned)n_ch, (unsigned)L), dim3(kHistThreads), 0, st,
                            idx, (long)n_per_ch, (int)n_ch, (long)E, counts, vec_ok);
         VBQ_CHECK_LAUNCH("hist_flat");
     } else {
@@ -151,7 +151,7 @@ int launch_hist(const uint16_t *idx, int64_t n_rows, int32_t n_ch, int32_t layou
         const size_t lds = sizeof(unsigned int) * kTileChannels * (T + 2);
         static bool attr_set = false;
         if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hist_tiled<N>),
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hist_tiled<N, CountT>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) {
                 set_error("hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
@@ -164,7 +164,7 @@ int launch_hist(const uint16_t *idx, int64_t n_rows, int32_t n_ch, int32_t layou
         const int64_t iters = (n_rows + 63) / 64;
         if (gx > iters) gx = iters;
         if (gx < 1) gx = 1;
-        hipLaunchKernelGGL((k_hist_tiled<N>), dim3((unsigned)gx, (unsigned)groups, (unsigned)L),
+        hipLaunchKernelGGL((k_hist_tiled<N, CountT>), dim3((unsigned)gx, (unsigned)groups, (unsigned)L),
                            dim3(kHistTiledThreads), lds, st, idx, (long)n_rows, (int)n_ch, (long)E, counts);
         VBQ_CHECK_LAUNCH("hist_tiled");
     }
@@ -300,27 +300,44 @@ k_transpose(const float *__restrict__ in, long rows, long cols, float *__restric
 }  // namespace
 }  // namespace vbq
 
-extern "C" int vbq_histogram_u16(const uint16_t *d_idx, int64_t n_rows, int32_t n_ch, int32_t layout,
-                                 int32_t n_lambda, int32_t N, int64_t *d_counts, void *stream) {
-    using namespace vbq;
-    VBQ_REQUIRE(n_rows == 0 || (d_idx && d_counts), VBQ_ERR_INVALID_ARGUMENT, "vbq_histogram_u16: null pointer argument");
+namespace vbq {
+namespace {
+template <typename CountT>
+int histogram_entry(const char *who, const uint16_t *d_idx, int64_t n_rows, int32_t n_ch, int32_t layout,
+                    int32_t n_lambda, int32_t N, CountT *cnt, void *stream) {
     VBQ_REQUIRE(n_rows >= 0 && n_ch >= 1 && n_lambda >= 1 && n_lambda <= 65535 && n_ch <= 65535,
-                VBQ_ERR_INVALID_ARGUMENT, "vbq_histogram_u16: bad sizes n_rows=%lld n_ch=%d n_lambda=%d",
-                (long long)n_rows, n_ch, n_lambda);
-    VBQ_REQUIRE(layout == VBQ_LAYOUT_BC || layout == VBQ_LAYOUT_CB, VBQ_ERR_INVALID_ARGUMENT,
-                "vbq_histogram_u16: unknown layout %d", layout);
+                VBQ_ERR_INVALID_ARGUMENT, "%s: bad sizes n_rows=%lld n_ch=%d n_lambda=%d", who, (long long)n_rows, n_ch,
+                n_lambda);
+    VBQ_REQUIRE(n_rows == 0 || (d_idx && cnt), VBQ_ERR_INVALID_ARGUMENT, "%s: null pointer argument", who);
+    VBQ_REQUIRE(layout == VBQ_LAYOUT_BC || layout == VBQ_LAYOUT_CB, VBQ_ERR_INVALID_ARGUMENT, "%s: unknown layout %d",
+                who, layout);
+    VBQ_REQUIRE(sizeof(CountT) == 8 || n_rows <= 0x7fffffffLL, VBQ_ERR_INVALID_ARGUMENT,
+                "%s: %lld rows per channel can overflow 32-bit counters", who, (long long)n_rows);
     if (n_rows == 0) return VBQ_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    unsigned long long *cnt = reinterpret_cast<unsigned long long *>(d_counts);
     switch (N) {
-        case 10: return launch_hist<10>(d_idx, n_rows, n_ch, layout, n_lambda, cnt, st);
-        case 8: return launch_hist<8>(d_idx, n_rows, n_ch, layout, n_lambda, cnt, st);
-        case 6: return launch_hist<6>(d_idx, n_rows, n_ch, layout, n_lambda, cnt, st);
-        case 4: return launch_hist<4>(d_idx, n_rows, n_ch, layout, n_lambda, cnt, st);
+        case 10: return launch_hist<10, CountT>(d_idx, n_rows, n_ch, layout, n_lambda, cnt, st);
+        case 8: return launch_hist<8, CountT>(d_idx, n_rows, n_ch, layout, n_lambda, cnt, st);
+        case 6: return launch_hist<6, CountT>(d_idx, n_rows, n_ch, layout, n_lambda, cnt, st);
+        case 4: return launch_hist<4, CountT>(d_idx, n_rows, n_ch, layout, n_lambda, cnt, st);
         default:
-            set_error("vbq_histogram_u16: max_bits_per_coord N=%d not built (have 4, 6, 8, 10)", N);
+            set_error("%s: max_bits_per_coord N=%d not built (have 4, 6, 8, 10)", who, N);
             return VBQ_ERR_UNSUPPORTED;
     }
+}
+}  // namespace
+}  // namespace vbq
+
+extern "C" int vbq_histogram_u16(const uint16_t *d_idx, int64_t n_rows, int32_t n_ch, int32_t layout,
+                                 int32_t n_lambda, int32_t N, int64_t *d_counts, void *stream) {
+    return vbq::histogram_entry<unsigned long long>("vbq_histogram_u16", d_idx, n_rows, n_ch, layout, n_lambda, N,
+                                                    reinterpret_cast<unsigned long long *>(d_counts), stream);
+}
+
+extern "C" int vbq_histogram_u16_i32(const uint16_t *d_idx, int64_t n_rows, int32_t n_ch, int32_t layout,
+                                     int32_t n_lambda, int32_t N, int32_t *d_counts, void *stream) {
+    return vbq::histogram_entry<unsigned int>("vbq_histogram_u16_i32", d_idx, n_rows, n_ch, layout, n_lambda, N,
+                                              reinterpret_cast<unsigned int *>(d_counts), stream);
 }
 
 extern "C" int vbq_moments_f32(const float *d_x, int64_t n_rows, int32_t n_ch, int32_t layout, double *d_out,

@@ -37,9 +37,17 @@ namespace {
 constexpr int kFastThreads = 256;
 constexpr int kFastNE = 4;
 
-__device__ __forceinline__ float dist_cost(float P, float mu, float sigma) {
+// Correctly rounded f32 quotient d / sigma without an f32 division: RN32(RN64(d * RN64(1/sigma))).
+// The f64 product is within 2^-52 (relative) of the true quotient, and a quotient of two f32 numbers
+// is never closer than 2^-49 (relative) to a midpoint between adjacent f32 values (A*2^24 -
+// (2M+1)*B is a non-zero integer for 24-bit A, B), so the final rounding sees the same side of every
+// rounding boundary as the exact quotient: the result is bit-identical to IEEE d / sigma.
+// v_cvt_f64_f32 + v_mul_f64 + v_cvt_f32_f64 = 12 cycles per wave64 against ~45 for the
+// v_div_scale / v_rcp / v_fma x5 / v_div_fmas / v_div_fixup expansion (21 quotients per element).
+// tests/test_host_logic.py::test_f64_reciprocal_division_identity checks the identity on 4e7 pairs.
+__device__ __forceinline__ float dist_cost(float P, float mu, double rinv) {
     const float d = __fsub_rn(P, mu);
-    const float t = __fdiv_rn(d, sigma);
+    const float t = (float)__dmul_rn((double)d, rinv);
     const float q = __fmul_rn(t, t);
     return __fmul_rn(0.5f, q);
 }
@@ -76,7 +84,7 @@ struct LevelInfo {
 // One step of the descent (see vbq_quantize.hip, search_and_score): visits level n of the
 // level-major table, returns both neighbours' costs/slots and advances g.
 template <int N>
-__device__ __forceinline__ LevelInfo<N> descend(const float *tb, int n, float z, float sg, uint32_t &g) {
+__device__ __forceinline__ LevelInfo<N> descend(const float *tb, int n, float z, double sg, uint32_t &g) {
     const int off = (1 << n) - 1;
     const int m = 1 << n;
     const uint32_t j = g;
@@ -106,7 +114,8 @@ __device__ __forceinline__ LevelInfo<N> descend(const float *tb, int n, float z,
 
 // Literal restatement of the reference scan for ONE element and ONE lambda (slow path).
 template <int N>
-__device__ __noinline__ uint32_t exact_rank_scan(const float *tb, float z, float sg, const float *pen) {
+__device__ __noinline__ uint32_t exact_rank_scan(const float *tb, float z, float sigma, const float *pen) {
+    const double sg = __ddiv_rn(1.0, (double)sigma);
     uint32_t g = 0;
     float bestL = 0.f, bestR = 0.f;
     uint32_t rkL = 0, rkR = 0;
@@ -169,13 +178,17 @@ k_quant_fast(const float *__restrict__ mu, const float *__restrict__ sg, long n_
         // ---------------- phase A: descent, per-level best cost + packed side info ----------------
         float du[NE][N1];
         uint32_t g[NE];
+        double rinv[NE];
 #pragma unroll
-        for (int k = 0; k < NE; ++k) g[k] = 0;
+        for (int k = 0; k < NE; ++k) {
+            g[k] = 0;
+            rinv[k] = __ddiv_rn(1.0, (double)s4[k]);
+        }
 #pragma unroll
         for (int n = 0; n <= N; ++n) {
 #pragma unroll
             for (int k = 0; k < NE; ++k) {
-                const LevelInfo<N> li = descend<N>(tb, n, m4[k], s4[k], g[k]);
+                const LevelInfo<N> li = descend<N>(tb, n, m4[k], rinv[k], g[k]);
                 const uint32_t rkL = ((2 * li.posL + 1) << (N - n)) - 1;
                 const uint32_t rkR = ((2 * li.posR + 1) << (N - n)) - 1;
                 const bool r_better = li.dR < li.dL;           // strict: on equal costs L keeps the level

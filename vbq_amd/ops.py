@@ -129,9 +129,10 @@ def quantize_notebook(means: torch.Tensor, stds: torch.Tensor, codebook_lm: torc
     return idx, val
 
 
-def histogram(idx: torch.Tensor, n_ch: int, *, N: int = 10, layout="bc", out: Optional[torch.Tensor] = None):
-    """K2 (vbq_histogram_u16).  idx: u16 [L, rows, C] / [L, C, rows] / [L, n].  Returns int64 [L, C, T]
-    (added into `out` when given)."""
+def histogram(idx: torch.Tensor, n_ch: int, *, N: int = 10, layout="bc", out: Optional[torch.Tensor] = None,
+              dtype=torch.int64):
+    """K2 (vbq_histogram_u16 / _i32).  idx: u16 [L, rows, C] / [L, C, rows] / [L, n].  Returns counts
+    [L, C, T] (added into `out` when given; `out.dtype` int64 or int32 selects the entry point)."""
     layout = _LAYOUTS[layout]
     idx = _dev(idx, torch.uint16, "idx")
     L = idx.shape[0]
@@ -141,13 +142,17 @@ def histogram(idx: torch.Tensor, n_ch: int, *, N: int = 10, layout="bc", out: Op
     rows = E // n_ch
     T = table_size(N)
     if out is None:
-        out = torch.zeros((L, n_ch, T), dtype=torch.int64, device=idx.device)
+        out = torch.zeros((L, n_ch, T), dtype=dtype, device=idx.device)
     else:
-        out = _dev(out, torch.int64, "out")
+        if out.dtype not in (torch.int64, torch.int32):
+            raise ValueError("out must be int64 or int32")
+        out = _dev(out, out.dtype, "out")
         if tuple(out.shape) != (L, n_ch, T):
             raise ValueError(f"out shape {tuple(out.shape)} != {(L, n_ch, T)}")
-    check(_lib.lib().vbq_histogram_u16(_ptr(idx), rows, n_ch, layout, L, N, _ptr(out), _stream(idx)),
-          "vbq_histogram_u16")
+    h = _lib.lib()
+    fn, name = (h.vbq_histogram_u16, "vbq_histogram_u16") if out.dtype == torch.int64 else \
+               (h.vbq_histogram_u16_i32, "vbq_histogram_u16_i32")
+    check(fn(_ptr(idx), rows, n_ch, layout, L, N, _ptr(out), _stream(idx)), name)
     return out
 
 
