@@ -47,7 +47,8 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
         raise RuntimeError("hipcc not found: cannot build libvbq_hip.so (ROCm toolchain required)")
     os.makedirs(LIBDIR, exist_ok=True)
     tmp = LIB + ".tmp"
-    cmd = [hipcc] + HIPCC_FLAGS + ["-I", INCLUDE, "-I", CSRC] + srcs + ["-o", tmp]
+    extra = os.environ.get("VBQ_EXTRA_HIPCC_FLAGS", "").split()       # developer experiments only
+    cmd = [hipcc] + HIPCC_FLAGS + extra + ["-I", INCLUDE, "-I", CSRC] + srcs + ["-o", tmp]
     if verbose:
         print(" ".join(cmd))
     r = subprocess.run(cmd, capture_output=True, text=True)

@@ -35,7 +35,13 @@ namespace vbq {
 namespace {
 
 constexpr int kFastThreads = 256;
-constexpr int kFastNE = 4;
+#ifndef VBQ_FAST_NE
+#define VBQ_FAST_NE 2
+#endif
+#ifndef VBQ_FAST_WAVES
+#define VBQ_FAST_WAVES 4
+#endif
+constexpr int kFastNE = VBQ_FAST_NE;      // elements per thread: 4 (16-B loads) or 2 (8-B loads)
 
 // Correctly rounded f32 quotient d / sigma without an f32 division: RN32(RN64(d * RN64(1/sigma))).
 // The f64 product is within 2^-52 (relative) of the true quotient, and a quotient of two f32 numbers
@@ -134,7 +140,7 @@ __device__ __noinline__ uint32_t exact_rank_scan(const float *tb, float z, float
 }
 
 template <int N, bool EXTRA>
-__global__ void __launch_bounds__(kFastThreads)
+__global__ void __launch_bounds__(kFastThreads, VBQ_FAST_WAVES)
 k_quant_fast(const float *__restrict__ mu, const float *__restrict__ sg, long n_per_ch, int C,
              const float *__restrict__ table, const float *__restrict__ pen, const float *__restrict__ len,
              int L, uint16_t *__restrict__ out_idx, float *__restrict__ out_zhat,
@@ -162,10 +168,17 @@ k_quant_fast(const float *__restrict__ mu, const float *__restrict__ sg, long n_
         const bool full = vec_ok && (i0 + NE <= n_per_ch);
         float m4[NE], s4[NE];
         if (full) {
-            const float4 mv = *reinterpret_cast<const float4 *>(mu + base + i0);
-            const float4 sv = *reinterpret_cast<const float4 *>(sg + base + i0);
-            m4[0] = mv.x; m4[1] = mv.y; m4[2] = mv.z; m4[3] = mv.w;
-            s4[0] = sv.x; s4[1] = sv.y; s4[2] = sv.z; s4[3] = sv.w;
+            if constexpr (NE == 4) {
+                const float4 mv = *reinterpret_cast<const float4 *>(mu + base + i0);
+                const float4 sv = *reinterpret_cast<const float4 *>(sg + base + i0);
+                m4[0] = mv.x; m4[1] = mv.y; m4[2] = mv.z; m4[3] = mv.w;
+                s4[0] = sv.x; s4[1] = sv.y; s4[2] = sv.z; s4[3] = sv.w;
+            } else {
+                const float2 mv = *reinterpret_cast<const float2 *>(mu + base + i0);
+                const float2 sv = *reinterpret_cast<const float2 *>(sg + base + i0);
+                m4[0] = mv.x; m4[1] = mv.y;
+                s4[0] = sv.x; s4[1] = sv.y;
+            }
         } else {
 #pragma unroll
             for (int k = 0; k < NE; ++k) {
@@ -264,13 +277,21 @@ k_quant_fast(const float *__restrict__ mu, const float *__restrict__ sg, long n_
                 }
             }
             if (full) {
-                uint2 pk2;
-                pk2.x = rank[0] | (rank[1] << 16);
-                pk2.y = rank[2] | (rank[3] << 16);
-                *reinterpret_cast<uint2 *>(out_idx + o) = pk2;
-                if (EXTRA) {
-                    if (out_zhat) *reinterpret_cast<float4 *>(out_zhat + o) = make_float4(zh[0], zh[1], zh[2], zh[3]);
-                    if (out_bits) *reinterpret_cast<float4 *>(out_bits + o) = make_float4(bt[0], bt[1], bt[2], bt[3]);
+                if constexpr (NE == 4) {
+                    uint2 pk2;
+                    pk2.x = rank[0] | (rank[1] << 16);
+                    pk2.y = rank[2] | (rank[3] << 16);
+                    *reinterpret_cast<uint2 *>(out_idx + o) = pk2;
+                    if (EXTRA) {
+                        if (out_zhat) *reinterpret_cast<float4 *>(out_zhat + o) = make_float4(zh[0], zh[1], zh[2], zh[3]);
+                        if (out_bits) *reinterpret_cast<float4 *>(out_bits + o) = make_float4(bt[0], bt[1], bt[2], bt[3]);
+                    }
+                } else {
+                    *reinterpret_cast<uint32_t *>(out_idx + o) = rank[0] | (rank[1] << 16);
+                    if (EXTRA) {
+                        if (out_zhat) *reinterpret_cast<float2 *>(out_zhat + o) = make_float2(zh[0], zh[1]);
+                        if (out_bits) *reinterpret_cast<float2 *>(out_bits + o) = make_float2(bt[0], bt[1]);
+                    }
                 }
             } else {
 #pragma unroll
@@ -296,8 +317,8 @@ int launch_quant_fast(const float *mu, const float *sg, int64_t n_per_ch, int32_
                       float *out_bits, int64_t E, int vec_ok, hipStream_t st) {
     const int64_t nquads = (n_per_ch + kFastNE - 1) / kFastNE;
     int64_t gx = (nquads + kFastThreads - 1) / kFastThreads;
-    // 3 workgroups per CU fit (53 KB of LDS each); keep every channel's share of the grid balanced
-    int64_t cap = (int64_t)256 * 3 * 4 / n_ch;
+    // 3 (NE=4: 53 KB LDS each) / 5 (NE=2) workgroups per CU fit; keep every channel's share balanced
+    int64_t cap = (int64_t)256 * (kFastNE == 4 ? 3 : 5) * 4 / n_ch;
     if (cap < 1) cap = 1;
     if (gx > cap) gx = cap;
     if (gx < 1) gx = 1;
