@@ -27,6 +27,9 @@ __device__ __forceinline__ unsigned int bin_slot(unsigned int q) { return q ^ (q
 // equal its first one and issues the other seven adds only where they differ (few active
 // lanes); (2) the lanes whose first index equals the wave leader's are summed with four
 // ballots and added by one lane.  Spread-out distributions pay ~10 extra VALU ops per index.
+constexpr int kHistCopies = 4;            // private copies of the bins per workgroup (lane & 3 picks one); 8 copies measured slower
+constexpr int kHistCopyStride = 2048 + 8; // words; +8 rotates each copy by 8 banks
+
 __device__ __forceinline__ void hist_add8(unsigned int *h, const uint4 v) {
     unsigned int s[8];
     {
@@ -53,11 +56,12 @@ __device__ __forceinline__ void hist_add8(unsigned int *h, const uint4 v) {
     const unsigned long long same_mask = __ballot(same);
     const int first = __ffsll((long long)same_mask) - 1;
     const int lane = threadIdx.x & 63;
-    if (lane == first) atomicAdd(&h[lead], tot);
-    if (!same) atomicAdd(&h[s[0]], cnt);
+    unsigned int *hc = h + (lane & (kHistCopies - 1)) * kHistCopyStride;   // this lane's copy of the bins
+    if (lane == first) atomicAdd(&hc[lead], tot);
+    if (!same) atomicAdd(&hc[s[0]], cnt);
 #pragma unroll
     for (int k = 1; k < 8; ++k)
-        if (!eq[k]) atomicAdd(&h[s[k]], 1u);
+        if (!eq[k]) atomicAdd(&hc[s[k]], 1u);
 }
 
 // All indices of the workgroup belong to one channel: [l][c][n_per_ch] contiguous.
@@ -66,9 +70,10 @@ __global__ void __launch_bounds__(kHistThreads)
 k_hist_flat(const uint16_t *__restrict__ idx, long n_per_ch, int C, long E,
             CountT *__restrict__ counts, int vec_ok) {
     constexpr int T = table_size(N);
-    __shared__ unsigned int h[T + 1];
+    static_assert(T + 1 <= 2048, "bin copies are laid out for at most 2048 bins");
+    __shared__ unsigned int h[kHistCopies * kHistCopyStride];
     const int c = blockIdx.y, l = blockIdx.z;
-    for (int i = threadIdx.x; i <= T; i += blockDim.x) h[i] = 0;
+    for (int i = threadIdx.x; i < kHistCopies * kHistCopyStride; i += blockDim.x) h[i] = 0;
     __syncthreads();
     const uint16_t *src = idx + (long)l * E + (long)c * n_per_ch;
     const long noct = vec_ok ? (n_per_ch >> 3) : 0;
@@ -96,7 +101,10 @@ k_hist_flat(const uint16_t *__restrict__ idx, long n_per_ch, int C, long E,
     __syncthreads();
     CountT *dst = counts + ((long)l * C + c) * T;
     for (int i = threadIdx.x; i < T; i += blockDim.x) {
-        const unsigned int v = h[bin_slot(i)];
+        const unsigned int sl = bin_slot(i);
+        unsigned int v = 0;
+#pragma unroll
+        for (int k = 0; k < kHistCopies; ++k) v += h[k * kHistCopyStride + sl];
         if (v) atomicAdd(&dst[i], (CountT)v);
     }
 }
