@@ -47,12 +47,18 @@ for cname, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
         pmc[k][cname + "_KiB_per_launch"] = sum(v) / len(v)
         pmc[k]["launches_" + sub] = len(v)
 out = {}
-for r in rows:
+merged = collections.OrderedDict()
+for r in rows:                      # template instantiations of one kernel are reported together
     k = short(r["Name"])
     if not k:
         continue
-    e = {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3, "min_us": float(r["MinNs"]) / 1e3,
-         "max_us": float(r["MaxNs"]) / 1e3, "pct": float(r["Percentage"])}
+    m = merged.setdefault(k, {"calls": 0, "total": 0.0, "min": 1e30, "max": 0.0, "pct": 0.0})
+    m["calls"] += int(r["Calls"]); m["total"] += float(r["TotalDurationNs"])
+    m["min"] = min(m["min"], float(r["MinNs"])); m["max"] = max(m["max"], float(r["MaxNs"]))
+    m["pct"] += float(r["Percentage"])
+for k, m in merged.items():
+    e = {"calls": m["calls"], "avg_us": m["total"] / m["calls"] / 1e3, "min_us": m["min"] / 1e3,
+         "max_us": m["max"] / 1e3, "pct": m["pct"]}
     e.update(pmc.get(k, {}))
     if "FETCH_SIZE_KiB_per_launch" in e and "WRITE_SIZE_KiB_per_launch" in e:
         e["hbm_read_bytes_corrected"] = 2 * e["FETCH_SIZE_KiB_per_launch"] * 1024

@@ -320,7 +320,17 @@ int launch_quant_fast(const float *mu, const float *sg, int64_t n_per_ch, int32_
     // 3 (NE=4: 53 KB LDS each) / 5 (NE=2) workgroups per CU fit; keep every channel's share balanced
     int64_t cap = (int64_t)256 * (kFastNE == 4 ? 3 : 5) * 4 / n_ch;
     if (cap < 1) cap = 1;
-    if (gx > cap) gx = cap;
+    if (gx > cap) {
+        // every workgroup walks ceil(iters / gx) chunks: pick the gx in [cap/2, cap] that wastes the
+        // fewest chunk slots (e.g. 72 chunks per channel: 18 workgroups x 4, not 20 x 3.6)
+        const int64_t iters = gx;
+        int64_t best = cap, best_pad = ((iters + cap - 1) / cap) * cap - iters;
+        for (int64_t g = cap - 1; g >= (cap + 1) / 2 && best_pad > 0; --g) {
+            const int64_t pad = ((iters + g - 1) / g) * g - iters;
+            if (pad * best < best_pad * g) { best = g; best_pad = pad; }
+        }
+        gx = best;
+    }
     if (gx < 1) gx = 1;
     const dim3 grid((unsigned)gx, (unsigned)n_ch), block(kFastThreads);
     if (out_zhat || out_bits)
