@@ -202,6 +202,14 @@ int vbq_bmshj_icdf_step_f32(const float *d_params, const float *d_xi, int64_t n_
                             float *d_left, float *d_right, float *d_mid, uint32_t *d_flags,
                             void *stream);
 
+/* Fit step of the prior (learned_prior.py:402-430: loss = -mean(log(pdf + 1e-10)), full batch).
+ * d_x_cb is f32 [n_ch][n_rows] (channel-major planes).  ADDS to d_out[c][0..42] the gradient of
+ * sum_rows -log(pdf+1e-10) with respect to the 43 effective parameters of channel c (same
+ * packing as above) and to d_out[c][43] that sum itself; f64.  The caller applies the
+ * softplus / tanh chain rule, the 1/(n_rows*n_ch) of reduce_mean and the optimiser. */
+int vbq_bmshj_nll_grad_f32(const float *d_params, const float *d_x_cb, int64_t n_rows, int32_t n_ch,
+                           double *d_out /* [n_ch][44] */, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -192,3 +192,57 @@ def test_quantize_facade():
     lag_ref = O.lagrangian(mu, sg, srt[wi[0, :, 0]] if False else srt[CO.quantize(mu, sg, tab, [0.37], N=N)[0, :, 0]],
                            lev[CO.quantize(mu, sg, tab, [0.37], N=N)[0, :, 0]], 0.37)
     assert abs(lag - lag_ref) <= 1e-5 * abs(lag_ref)
+
+
+def _torch_nll(raw, x):
+    """f64 torch restatement of loss = -mean(log(pdf + 1e-10)) with pdf = d cdf / dx by autograd
+    (learned_prior.py:150-171, 405-408): the independent reference for the hand-written gradient."""
+    mats, bias, fac = raw
+    xx = x.clone().requires_grad_(True)                       # [n, C]
+    h = xx.t()[:, None, :]                                    # [C, 1, n]
+    for i in range(4):
+        h = torch.matmul(torch.nn.functional.softplus(mats[i]), h) + bias[i]
+        if i < 3:
+            h = h + torch.tanh(fac[i]) * torch.tanh(h)
+    cdf = torch.sigmoid(h)[:, 0, :].t()                       # [n, C]
+    pdf, = torch.autograd.grad(cdf.sum(), xx, create_graph=True)
+    return -(torch.log(pdf + 1e-10)).mean()
+
+
+def test_bmshj_fit_gradient_and_convergence():
+    from vbq_amd import ops, priors
+    rng = np.random.default_rng(4)
+    C, n = 3, 4000
+    p = priors.BMSHJ2018Prior(C, init_scale=2.0, seed=5)
+    p.set_weights([w + rng.normal(0, 0.2, w.shape).astype(np.float32) for w in p.get_weights()])
+    data = np.stack([rng.normal(0.5, 0.7, n), rng.standard_t(4, n) * 0.5,
+                     np.where(rng.random(n) < 0.5, rng.normal(-1, 0.3, n), rng.normal(1.2, 0.4, n))], axis=1).astype(np.float32)
+    x_cb = ops.transpose(torch.from_numpy(data).cuda())
+    loss, grads = p.loss_and_grads(x_cb)
+    raw = ([torch.tensor(m, dtype=torch.float64, requires_grad=True) for m in p.matrices],
+           [torch.tensor(b, dtype=torch.float64, requires_grad=True) for b in p.biases],
+           [torch.tensor(f, dtype=torch.float64, requires_grad=True) for f in p.factors])
+    ref = _torch_nll(raw, torch.tensor(data, dtype=torch.float64))
+    ref.backward()
+    assert loss == pytest.approx(float(ref), rel=2e-5)
+    want = []
+    for i in range(4):
+        want += [raw[0][i].grad.numpy(), raw[1][i].grad.numpy()] + ([raw[2][i].grad.numpy()] if i < 3 else [])
+    for g, w in zip(grads, want):
+        assert g.shape == w.shape
+        assert np.allclose(g, w, rtol=5e-3, atol=2e-5), np.abs(g - w).max()
+    # the fit: NLL goes down and ends below a single Gaussian's on the bimodal channel
+    p2 = priors.BMSHJ2018Prior(C, init_scale=1.0, seed=1)
+    l0, _ = p2.loss_and_grads(x_cb)
+    rec = p2.fit(data, lr=0.1, its=150, tol=1e-2, logging_freq=10)          # post_process.py:78 settings, fewer its
+    assert len(rec) >= 15 and rec[-1]["loss"] < rec[0]["loss"] < l0
+    assert p2.last_loss < l0 - 0.3
+    lp = p2.logpdf(data)
+    gauss_nll = 0.5 * np.log(2 * np.pi * data[:, 2].var()) + 0.5
+    assert -lp[:, 2].mean() < gauss_nll
+    xi = np.repeat(O.dyadic_xi(6)[:, None], C, axis=1)
+    z = p2.inverse_cdf(xi)
+    assert np.all(np.diff(z[np.argsort(O.dyadic_xi(6))], axis=0) > 0)         # a usable, monotone code book
+    q = np.quantile(data, [0.25, 0.5, 0.75], axis=0)                          # fitted quartiles ~ empirical
+    zq = p2.inverse_cdf(np.repeat(np.array([0.25, 0.5, 0.75])[:, None], C, axis=1))
+    assert np.allclose(zq, q, atol=0.15)

@@ -127,3 +127,149 @@ extern "C" int vbq_bmshj_icdf_step_f32(const float *d_params, const float *d_xi,
     VBQ_CHECK_LAUNCH("bmshj_icdf_step");
     return VBQ_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// Fit step of the prior (learned_prior.py:363-465, the "next" row f1 of SURVEY 8f):
+//   loss = -mean(log(pdf(x) + 1e-10)),  full batch.
+// One pass accumulates, per channel, sum(-log(pdf+1e-10)) and its gradient with respect to the
+// 43 EFFECTIVE parameters by hand-written reverse mode through the value path (h) and the
+// tangent path (v = dh/dx) of the 4-layer map; the host applies the softplus / tanh chain rule
+// and Adam (43*C numbers).  x is read as channel-major planes so that a workgroup has its 43
+// parameters in scalar registers and every thread keeps 44 private partial sums.
+// ------------------------------------------------------------------------------------------
+namespace vbq {
+namespace {
+
+constexpr int kNP = VBQ_BMSHJ_PARAMS_PER_CHANNEL;
+
+__device__ __forceinline__ void bmshj_nll_grad(const float *__restrict__ P, float x, float (&g)[kNP + 1]) {
+    // ---- forward, keeping what the backward pass needs
+    float a[3][3], t[3][3], gg[3][3], u[3][3], h[3][3], v[3][3];     // [layer][unit]
+    // layer 0 (3x1): h_-1 = x, v_-1 = 1
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const float M = P[r], b = P[3 + r], f = P[6 + r];
+        a[0][r] = M * x + b;
+        u[0][r] = M;
+        t[0][r] = tanhf(a[0][r]);
+        gg[0][r] = 1.0f + f * (1.0f - t[0][r] * t[0][r]);
+        h[0][r] = a[0][r] + f * t[0][r];
+        v[0][r] = gg[0][r] * u[0][r];
+    }
+#pragma unroll
+    for (int L = 1; L <= 2; ++L) {
+        const float *Q = P + 9 + 15 * (L - 1);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const float f = Q[12 + r];
+            a[L][r] = Q[3 * r] * h[L - 1][0] + Q[3 * r + 1] * h[L - 1][1] + Q[3 * r + 2] * h[L - 1][2] + Q[9 + r];
+            u[L][r] = Q[3 * r] * v[L - 1][0] + Q[3 * r + 1] * v[L - 1][1] + Q[3 * r + 2] * v[L - 1][2];
+            t[L][r] = tanhf(a[L][r]);
+            gg[L][r] = 1.0f + f * (1.0f - t[L][r] * t[L][r]);
+            h[L][r] = a[L][r] + f * t[L][r];
+            v[L][r] = gg[L][r] * u[L][r];
+        }
+    }
+    const float *Q3 = P + 39;
+    const float a3 = Q3[0] * h[2][0] + Q3[1] * h[2][1] + Q3[2] * h[2][2] + Q3[3];
+    const float u3 = Q3[0] * v[2][0] + Q3[1] * v[2][1] + Q3[2] * v[2][2];
+    const float s = 1.0f / (1.0f + expf(-a3));
+    const float sp = s * (1.0f - s);
+    const float pdf = sp * u3;
+    const float pe = pdf + 1e-10f;
+    g[kNP] += -logf(pe);
+    // ---- backward of L = -log(pdf + eps)
+    const float pb = -1.0f / pe;
+    float ab = pb * u3 * sp * (1.0f - 2.0f * s);       // dL/da3
+    float ub = pb * sp;                                 // dL/du3
+    float hb[3], vb[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        g[39 + d] += ab * h[2][d] + ub * v[2][d];
+        hb[d] = Q3[d] * ab;
+        vb[d] = Q3[d] * ub;
+    }
+    g[42] += ab;
+#pragma unroll
+    for (int L = 2; L >= 1; --L) {
+        const float *Q = P + 9 + 15 * (L - 1);
+        float *G = g + 9 + 15 * (L - 1);
+        float abv[3], ubv[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const float f = Q[12 + r];
+            const float omt = 1.0f - t[L][r] * t[L][r];
+            G[12 + r] += hb[r] * t[L][r] + vb[r] * u[L][r] * omt;
+            abv[r] = hb[r] * gg[L][r] + vb[r] * u[L][r] * f * (-2.0f * t[L][r] * omt);
+            ubv[r] = vb[r] * gg[L][r];
+            G[9 + r] += abv[r];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) G[3 * r + d] += abv[r] * h[L - 1][d] + ubv[r] * v[L - 1][d];
+        }
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            hb[d] = Q[d] * abv[0] + Q[3 + d] * abv[1] + Q[6 + d] * abv[2];
+            vb[d] = Q[d] * ubv[0] + Q[3 + d] * ubv[1] + Q[6 + d] * ubv[2];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const float f = P[6 + r];
+        const float omt = 1.0f - t[0][r] * t[0][r];
+        g[6 + r] += hb[r] * t[0][r] + vb[r] * u[0][r] * omt;
+        const float a0b = hb[r] * gg[0][r] + vb[r] * u[0][r] * f * (-2.0f * t[0][r] * omt);
+        const float u0b = vb[r] * gg[0][r];
+        g[3 + r] += a0b;
+        g[r] += a0b * x + u0b;             // h_-1 = x, v_-1 = 1
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_bmshj_nll_grad(const float *__restrict__ params, const float *__restrict__ x_cb, long n_rows,
+                 double *__restrict__ out) {
+    const int c = blockIdx.y;
+    __shared__ float P[kNP + 1];
+    __shared__ double red[4][kNP + 1];
+    if (threadIdx.x < kNP) P[threadIdx.x] = params[(long)c * kNP + threadIdx.x];
+    __syncthreads();
+    float Pl[kNP];
+#pragma unroll
+    for (int i = 0; i < kNP; ++i) Pl[i] = P[i];
+    float g[kNP + 1];
+#pragma unroll
+    for (int i = 0; i <= kNP; ++i) g[i] = 0.0f;
+    const float *src = x_cb + (long)c * n_rows;
+    for (long r = (long)blockIdx.x * blockDim.x + threadIdx.x; r < n_rows; r += (long)gridDim.x * blockDim.x)
+        bmshj_nll_grad(Pl, src[r], g);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i <= kNP; ++i) {
+        double s = (double)g[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+        if (lane == 0) red[w][i] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x <= kNP) {
+        const int i = threadIdx.x;
+        atomicAdd(&out[(long)c * (kNP + 1) + i], (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]));
+    }
+}
+
+}  // namespace
+}  // namespace vbq
+
+extern "C" int vbq_bmshj_nll_grad_f32(const float *d_params, const float *d_x_cb, int64_t n_rows, int32_t n_ch,
+                                      double *d_out, void *stream) {
+    using namespace vbq;
+    VBQ_REQUIRE(n_rows >= 0 && n_ch >= 1 && n_ch <= 65535, VBQ_ERR_INVALID_ARGUMENT, "vbq_bmshj_nll_grad_f32: bad sizes");
+    if (n_rows == 0) return VBQ_OK;
+    VBQ_REQUIRE(d_params && d_x_cb && d_out, VBQ_ERR_INVALID_ARGUMENT, "vbq_bmshj_nll_grad_f32: null pointer argument");
+    int64_t gx = (n_rows + 256 * 8 - 1) / (256 * 8);
+    const int64_t cap = 4096 / n_ch + 1;
+    if (gx > cap) gx = cap;
+    hipLaunchKernelGGL(k_bmshj_nll_grad, dim3((unsigned)gx, (unsigned)n_ch), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), d_params, d_x_cb, (long)n_rows, d_out);
+    VBQ_CHECK_LAUNCH("bmshj_nll_grad");
+    return VBQ_OK;
+}

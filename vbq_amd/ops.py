@@ -253,3 +253,18 @@ def bmshj_icdf_step(params, xi, left, right, mid, flags):
     rows = xi.numel() // Cc
     check(_lib.lib().vbq_bmshj_icdf_step_f32(_ptr(params), _ptr(xi), rows, Cc, _ptr(left), _ptr(right), _ptr(mid),
                                              _ptr(flags), _stream(xi)), "vbq_bmshj_icdf_step_f32")
+
+
+def bmshj_nll_grad(params: torch.Tensor, x_cb: torch.Tensor, out: Optional[torch.Tensor] = None):
+    """K4 (vbq_bmshj_nll_grad_f32).  params f32 [C, 43] effective; x_cb f32 [C, n] planes.
+    Returns f64 [C, 44]: d(sum -log(pdf+1e-10))/d(params) and, in column 43, the sum itself."""
+    params = _dev(params, torch.float32, "params")
+    x_cb = _dev(x_cb, torch.float32, "x_cb")
+    Cc, n = x_cb.shape
+    if tuple(params.shape) != (Cc, _lib.BMSHJ_PARAMS_PER_CHANNEL):
+        raise ValueError(f"params must be [{Cc}, 43], got {tuple(params.shape)}")
+    if out is None:
+        out = torch.zeros((Cc, 44), dtype=torch.float64, device=x_cb.device)
+    check(_lib.lib().vbq_bmshj_nll_grad_f32(_ptr(params), _ptr(x_cb), n, Cc, _ptr(out), _stream(x_cb)),
+          "vbq_bmshj_nll_grad_f32")
+    return out

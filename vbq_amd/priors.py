@@ -164,6 +164,70 @@ class BMSHJ2018Prior:
         c, p, _ = ops.bmshj_cdf_pdf(self._params(), self._x(inputs), cdf=True, pdf=True)
         return self._ret(c, inputs), self._ret(p, inputs)
 
+    # ---- fit (learned_prior.py:363-465) -------------------------------------------------------
+    def loss_and_grads(self, x_cb: torch.Tensor):
+        """-mean(log(pdf + 1e-10)) over all elements (learned_prior.py:405-408) and its gradient with
+        respect to the RAW variables, in get_weights() order.  x_cb: f32 device planes [C, n]."""
+        Cc, n = x_cb.shape
+        out = ops.bmshj_nll_grad(self._params(), x_cb).cpu().numpy()            # [C, 44] f64
+        scale = 1.0 / (float(n) * Cc)
+        loss = float(out[:, 43].sum() * scale)
+        g = out[:, :43] * scale
+        grads, o = [], 0
+        for i in range(4):
+            m = self.matrices[i]
+            k = m[0].size
+            gm = g[:, o:o + k].reshape(m.shape); o += k
+            sig = 1.0 / (1.0 + np.exp(-m.astype(np.float64)))                    # d softplus / d raw
+            grads.append((gm * sig).astype(np.float32))
+            b = self.biases[i]
+            k = b[0].size
+            grads.append(g[:, o:o + k].reshape(b.shape).astype(np.float32)); o += k
+            if i < 3:
+                f = self.factors[i]
+                k = f[0].size
+                gf = g[:, o:o + k].reshape(f.shape); o += k
+                grads.append((gf * (1.0 - np.tanh(f.astype(np.float64)) ** 2)).astype(np.float32))   # d tanh / d raw
+        return loss, grads
+
+    def fit(self, data, lr=0.01, its=500, tol=1e-3, logging_freq=10, verbose=False, early_stop=False):
+        """Full-batch Adam on the negative log-likelihood, as learned_prior.train
+        (learned_prior.py:363-465; post_process.py:73-81 calls it with --lr 0.1 --its 400 --tol 1e-2).
+        `data` is [n, C] (the validation latent means).  Returns the record list [{it, loss}, ...].
+
+        The reference tests |prev_loss - loss| / |loss| < tol after every step (:427) but never
+        assigns prev_loss (it stays inf, :421), so its loop always runs all `its` iterations.
+        That behaviour is the default here; early_stop=True applies the evidently intended rule."""
+        x = data if isinstance(data, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(data)))
+        x = x.to(_device(), torch.float32).reshape(-1, self._channels).contiguous()
+        x_cb = ops.transpose(x)
+        beta1, beta2, eps = 0.9, 0.999, 1e-8                                     # tf.train.AdamOptimizer defaults
+        weights = [w.copy() for w in self.get_weights()]
+        m = [np.zeros_like(w) for w in weights]
+        v = [np.zeros_like(w) for w in weights]
+        record = []
+        prev_loss = float("inf")
+        _, grads = self.loss_and_grads(x_cb)
+        for it in range(its):
+            t = it + 1
+            lr_t = lr * np.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t)
+            for k in range(len(weights)):
+                m[k] = (beta1 * m[k] + (1.0 - beta1) * grads[k]).astype(np.float32)
+                v[k] = (beta2 * v[k] + (1.0 - beta2) * grads[k] * grads[k]).astype(np.float32)
+                weights[k] = (weights[k] - lr_t * m[k] / (np.sqrt(v[k]) + eps)).astype(np.float32)
+            self.set_weights(weights)
+            loss_, grads = self.loss_and_grads(x_cb)                             # loss after the step (:423)
+            if early_stop:
+                if abs(prev_loss - loss_) / abs(loss_) < tol:
+                    break
+                prev_loss = loss_
+            if it % logging_freq == 0 or it + 1 == its:
+                record.append(dict(it=it, loss=loss_))
+                if verbose:
+                    print("it=%d,\t\tloss=%g" % (it, loss_))
+        self.last_loss = loss_
+        return record
+
     def inverse_cdf(self, xi, method="bisection", max_iterations=1000, tol=1e-9, **kwargs):
         """learned_prior.py:173-218: global bracket doubling, masked bisection, the reference's
         stopping rule (all mid values exactly 0, or the smallest bracket <= tol)."""
