@@ -161,3 +161,27 @@ def test_bmshj_self_consistency():
     z = p.inverse_cdf(xi)
     assert z.dtype == np.float32
     assert np.allclose(p.cdf(z), xi, atol=2e-6)
+
+
+def test_cfg1_single_image_plumbing():
+    """BASELINE.json configs[0]: one Kodak image's latents ([1536 x C], here C = 32), one lambda, on the
+    CPU restatement only -- the reference's own CPU-runnable case, end to end through the two
+    entropy-model passes and the compress_latents dict (quantizer.py:82-150, 190-240)."""
+    rng = np.random.default_rng(42)
+    B, C = 1536, 32
+    scale = np.exp(rng.uniform(np.log(0.3), np.log(3.0), C))
+    orc = O.ChannelwiseOracle(C, N)
+    orc.build_code_points(O.factored_gaussian_icdf(np.zeros(C), scale))
+    mu = (scale * rng.normal(0, 1, (B, C))).astype(np.float32)
+    sg = np.clip(np.exp(rng.normal(-2, 0.7, (B, C))), 1e-4, 10).astype(np.float32)
+    lam = [np.float32(0.5)]
+    orc.build_entropy_models(mu, sg, lam, add_n_smoothing=1)
+    out = orc.compress_latents(mu, sg, lam)
+    z, nb = out["Z_hat"][lam[0]], out["num_bits"][lam[0]]
+    assert z.shape == (B, C) and nb.shape == (B, C) and nb.dtype == np.float32
+    q = O.qidx_lookup(orc.by_channel, z)
+    assert np.array_equal(np.take_along_axis(orc.by_channel, q, axis=1), z.T)          # quantizer.py:136-137
+    bpl = float(nb.sum()) / (B * C)                                                    # bits per latent
+    assert 0.5 < bpl < 8.0
+    d = O.lagrangian(mu, sg, z, out["raw_num_bits"][lam[0]], 0.5)
+    assert np.isfinite(d) and d > 0

@@ -30,12 +30,17 @@ def short(name):
     return None
 
 
-stats = glob.glob(os.path.join(src, f"{tag}_stats", "*", "*_kernel_stats.csv"))[0]
+def newest(pattern):
+    fs = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return fs[-1:] if fs else []
+
+
+stats = newest(os.path.join(src, f"{tag}_stats", "*", "*_kernel_stats.csv"))[0]
 shutil.copy(stats, os.path.join(dst, f"{tag}_kernel_stats.csv"))
 rows = list(csv.DictReader(open(stats)))
 pmc = collections.defaultdict(dict)
 for cname, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
-    f = glob.glob(os.path.join(src, f"{tag}_{sub}", "*", "*_counter_collection.csv"))
+    f = newest(os.path.join(src, f"{tag}_{sub}", "*", "*_counter_collection.csv"))
     if not f:
         continue
     acc = collections.defaultdict(list)
