@@ -281,3 +281,26 @@ def test_large_roundtrip_properties(ops):
     # spot-check 2 lambdas against the oracle at full size
     want = CO.quantize(mu, sg, tab, [LAM32[3], LAM32[20]], N=N, threads=8)
     assert np.array_equal(host(idx)[[3, 20]], want)
+
+
+def test_fast_kernel_tie_machinery():
+    """The fast K1 decides rare ties by re-solving flagged lanes with the literal 21-candidate scan.
+    (1) With every solve forced through that scan the result is still bit-identical to the oracle;
+    (2) with the flags switched off mismatches appear on the same data -- i.e. the adversarial data
+    does reach the tie cases and the flags are what keeps the fast path exact."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "tools", "stress_parity.py"), "--n", "1000000", "--rounds", "3"]
+
+    def run(dbg):
+        env = dict(os.environ, VBQ_FAST_DEBUG=str(dbg))
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        return r.returncode, r.stdout
+    rc0, out0 = run(0)
+    assert rc0 == 0, out0
+    rc1, out1 = run(1)
+    assert rc1 == 0, out1
+    rc2, out2 = run(2)
+    assert rc2 == 1 and "mismatches 0\n" not in out2.splitlines()[-1] + "\n", out2

@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Large randomized parity stress: HIP K1 (fast plane kernel) vs the C oracle, bit for bit.
+    python tools/stress_parity.py [--n 4000000] [--rounds 6]
+Covers raw and corrected (random) lengths, narrow / wide / duplicate tables, tiny and huge
+sigma, mu on and between code points, and the f64-score mode."""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from scipy.stats import norm
+
+from oracle import c_oracle as CO
+from vbq_amd import ops
+
+N = 10
+XI = np.concatenate([(np.arange(2 ** n) + 0.5) / 2 ** n for n in range(N + 1)])
+LAM = [float(v) for v in 2.0 ** np.linspace(-8, 7.5, 32)]
+
+
+def case(rng, kind, n):
+    scale = float(np.exp(rng.uniform(np.log(0.05), np.log(20.0))))
+    tab = norm.ppf(XI, scale=scale)
+    if kind == "dup":
+        tab = np.round(tab / scale * 40) / 40 * scale
+    if kind == "t":
+        from scipy.stats import t as tdist
+        tab = tdist.ppf(XI, df=3) * scale
+    tab = tab.astype(np.float32)[None]
+    mu = (scale * rng.standard_t(4, n)).astype(np.float32)
+    sg = np.exp(rng.normal(-2, 1.5, n)).astype(np.float32) * np.float32(scale)
+    srt = np.sort(tab[0])
+    k = n // 20
+    mu[:k] = srt[rng.integers(0, 2047, k)]                                   # exact hits
+    j = rng.integers(0, 2046, k)
+    mu[k:2 * k] = (0.5 * (srt[j].astype(np.float64) + srt[j + 1])).astype(np.float32)   # mid-points: L/R ties
+    mu[2 * k:2 * k + 100] = np.float32(1e6) * scale
+    sg[3 * k:3 * k + 1000] = np.float32(1e-6) * scale
+    sg[3 * k + 1000:3 * k + 2000] = np.float32(1e4) * scale
+    level_len = None
+    if kind in ("corr", "dup"):
+        ov = np.abs(rng.normal(0, 2.0, (len(LAM), 1, N + 1))).astype(np.float32)
+        level_len = (np.arange(N + 1, dtype=np.float32)[None, None, :] + ov).astype(np.float32)
+    return tab, mu, sg, level_len
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=4_000_000)
+    ap.add_argument("--rounds", type=int, default=6)
+    args = ap.parse_args()
+    dev = torch.device("cuda")
+    rng = np.random.default_rng(2024)
+    total = bad = 0
+    kinds = ["raw", "corr", "dup", "t", "raw", "corr"]
+    for r in range(args.rounds):
+        kind = kinds[r % len(kinds)]
+        tab, mu, sg, ll = case(rng, kind, args.n)
+        t0 = time.time()
+        want = CO.quantize(mu, sg, tab, LAM, N=N, level_len=ll, threads=CO.max_threads())[:, :, 0]
+        t1 = time.time()
+        got = ops.quantize(torch.from_numpy(mu).to(dev), torch.from_numpy(sg).to(dev), torch.from_numpy(tab).to(dev), LAM,
+                           N=N, level_len=None if ll is None else torch.from_numpy(ll).to(dev)).cpu().numpy()
+        nb = int(np.count_nonzero(got != want))
+        total += got.size
+        bad += nb
+        print(f"round {r} [{kind:4s}] {got.size:.3g} latents: mismatches {nb}   (oracle {t1 - t0:.1f} s)", flush=True)
+        if kind == "raw":
+            w64 = CO.quantize(mu[:500000], sg[:500000], tab, LAM, N=N, mode=1, threads=CO.max_threads())[:, :, 0]
+            g64 = ops.quantize(torch.from_numpy(mu[:500000]).to(dev), torch.from_numpy(sg[:500000]).to(dev),
+                               torch.from_numpy(tab).to(dev), LAM, N=N, mode="f64").cpu().numpy()
+            nb = int(np.count_nonzero(g64 != w64))
+            total += g64.size
+            bad += nb
+            print(f"        [f64 ] {g64.size:.3g} latents: mismatches {nb}", flush=True)
+    print(f"TOTAL {total:.4g} latents compared, {bad} mismatches")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()

@@ -29,6 +29,8 @@
 //          is raised when it is <= 2^-21 * S.
 //    A wave with any flagged lane re-solves those lanes for that lambda with the literal
 //    21-candidate scan (exact_rank_scan).  Both events have probability ~1e-6 per solve.
+#include <stdlib.h>
+
 #include "vbq_common.h"
 
 namespace vbq {
@@ -144,10 +146,13 @@ __global__ void __launch_bounds__(kFastThreads, VBQ_FAST_WAVES)
 k_quant_fast(const float *__restrict__ mu, const float *__restrict__ sg, long n_per_ch, int C,
              const float *__restrict__ table, const float *__restrict__ pen, const float *__restrict__ len,
              int L, uint16_t *__restrict__ out_idx, float *__restrict__ out_zhat,
-             float *__restrict__ out_bits, long E, int vec_ok) {
+             float *__restrict__ out_bits, long E, int vec_ok, int dbg) {
     constexpr int T = table_size(N);
     constexpr int N1 = N + 1;
     constexpr int NE = kFastNE;
+    // dbg (tests only, VBQ_FAST_DEBUG): 1 = send every solve through the literal scan,
+    // 2 = never flag (shows that the flags are what keeps the fast path exact)
+    const bool force_slow = dbg == 1, never_flag = dbg == 2;
     constexpr int PS = (N1 + 3) & ~3;                 // penalty row padded to whole 16-B reads
     __shared__ float tb[T + 1];
     __shared__ uint32_t scratch[N1 * NE * kFastThreads];
@@ -255,7 +260,7 @@ k_quant_fast(const float *__restrict__ mu, const float *__restrict__ sg, long n_
                 const uint32_t thr = __float_as_uint(__fmul_rn(S[k], 4.76837158203125e-07f));
                 const bool lr_close = (pk[k] & 0x7fe00000u) <= thr;
                 rank[k] = pk[k] & 0x7ffu;
-                flagged[k] = multi || lr_close;
+                flagged[k] = ((multi || lr_close) && !never_flag) || force_slow;
                 any_flag = any_flag || flagged[k];
             }
             if (__any(any_flag)) {
@@ -333,12 +338,13 @@ int launch_quant_fast(const float *mu, const float *sg, int64_t n_per_ch, int32_
     }
     if (gx < 1) gx = 1;
     const dim3 grid((unsigned)gx, (unsigned)n_ch), block(kFastThreads);
+    static const int dbg = [] { const char *e = getenv("VBQ_FAST_DEBUG"); return e ? atoi(e) : 0; }();
     if (out_zhat || out_bits)
         hipLaunchKernelGGL((k_quant_fast<N, true>), grid, block, 0, st, mu, sg, (long)n_per_ch, (int)n_ch, table, pen,
-                           len, (int)L, out_idx, out_zhat, out_bits, (long)E, vec_ok);
+                           len, (int)L, out_idx, out_zhat, out_bits, (long)E, vec_ok, dbg);
     else
         hipLaunchKernelGGL((k_quant_fast<N, false>), grid, block, 0, st, mu, sg, (long)n_per_ch, (int)n_ch, table, pen,
-                           len, (int)L, out_idx, out_zhat, out_bits, (long)E, vec_ok);
+                           len, (int)L, out_idx, out_zhat, out_bits, (long)E, vec_ok, dbg);
     VBQ_CHECK_LAUNCH("quant_fast");
     return VBQ_OK;
 }
