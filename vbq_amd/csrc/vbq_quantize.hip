@@ -361,7 +361,8 @@ int launch_quantize(const float *mu, const float *sg, int64_t n_rows, int32_t n_
             if (gx < 1) gx = 1;
             // The fast kernel's tie certificate needs lambda*len to be 0 or comfortably normal.
             bool fast_ok = sizeof(PenT) == 4 && !force_plain_kernel();
-            for (int i = 0; i < Lc; ++i) fast_ok = fast_ok && (lc.lam[i] == 0.0 || lc.lam[i] >= 5.4e-20);
+            // (vbq_quantize_fast.hip: the equality mask needs every lambda*len >= 2^-39 for len >= 1)
+            for (int i = 0; i < Lc; ++i) fast_ok = fast_ok && (lc.lam[i] >= 1.9e-12 && lc.lam[i] <= 1.8e19);
             if constexpr (sizeof(PenT) == 4) {
                 if (fast_ok) {
                     const int r = launch_quant_fast<N>(mu, sg, n_per_ch, n_ch, table, pen, len_c, Lc, oi, oz, ob, E,

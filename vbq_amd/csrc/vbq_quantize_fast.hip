@@ -43,6 +43,9 @@ constexpr int kFastThreads = 256;
 #ifndef VBQ_FAST_WAVES
 #define VBQ_FAST_WAVES 4
 #endif
+#ifndef VBQ_FAST_PKMASK
+#define VBQ_FAST_PKMASK 0     // equality mask by v_sub + v_alignbit (0) or by packed FMAs (1: measured 6 % slower)
+#endif
 constexpr int kFastNE = VBQ_FAST_NE;      // elements per thread: 4 (16-B loads) or 2 (8-B loads)
 
 // Correctly rounded f32 quotient d / sigma without an f32 division: RN32(RN64(d * RN64(1/sigma))).
@@ -61,6 +64,44 @@ __device__ __forceinline__ float dist_cost(float P, float mu, double rinv) {
 }
 
 __device__ __forceinline__ float min3f(float a, float b, float c) { return fminf(fminf(a, b), c); }
+
+// Packed-f32 helpers (one VOP3P instruction handles the two elements of a thread; v_pk_fma_f32
+// issues in 4 cycles per wave64 = 2 cycles per FMA, the cheapest arithmetic on the chip).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// clamp(a * b + c) to [0, 1], per half
+__device__ __forceinline__ f32x2 pk_fma_clamp01(f32x2 a, f32x2 b, f32x2 c) {
+    f32x2 d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
+// a * b + c, per half (exact for the small integers it is used on)
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) {
+    f32x2 d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
+// Bit mask sum_n ind[n] * 2^n of M 0/1 indicators as a balanced tree of packed FMAs (depth
+// ceil(log2 M) instead of a serial Horner chain; the weights 2^(2^j) live in registers).
+template <int M>
+__device__ __forceinline__ f32x2 pk_bitmask(f32x2 (&v)[M]) {
+    int m = M;
+    float w = 2.0f;
+#pragma unroll
+    for (int pass = 0; pass < 5; ++pass) {
+        if (m <= 1) break;
+        const f32x2 w2 = {w, w};
+        int o = 0;
+#pragma unroll
+        for (int i = 0; i + 1 < m; i += 2) v[o++] = pk_fma(v[i + 1], w2, v[i]);
+        if (m & 1) v[o++] = v[m - 1];
+        m = o;
+        w = w * w;
+    }
+    return v[0];
+}
 
 // Minimum of M values as a tree of v_min3_f32 (ceil((M-1)/2) instructions).
 template <int M>
@@ -240,13 +281,34 @@ k_quant_fast(const float *__restrict__ mu, const float *__restrict__ sg, long n_
 #pragma unroll
             for (int k = 0; k < NE; ++k) S[k] = min_of<N1>(cst[k]);
             uint32_t ne[NE];                                    // bit n set <=> cost_n != S
+            if constexpr (NE == 2 && VBQ_FAST_PKMASK) {
+                // ind_n = clamp((c_n - S) * 2^64) is exactly 0 where c_n == S and exactly 1 elsewhere:
+                // scaling by a power of two commutes with the rounding of c_n - S; a non-zero difference is
+                // >= ulp(S) >= 2^-64 when S >= 2^-40, and when S < 2^-40 the winner is level 0 and every
+                // other level costs >= lambda * 1 >= 2^-39 (the launcher routes smaller lambdas to the plain
+                // kernel).  Overflow gives +inf -> 1; S >= 2^64 gives NaN -> a mask the popcount test flags.
+                // mask = sum_n ind_n * 2^n by a tree of packed FMAs, exact in f32.
+                const float H = 18446744073709551616.0f;        // 2^64
+                const f32x2 H2 = {H, H};
+                const f32x2 nSH = {-(S[0] * H), -(S[1] * H)};
+                f32x2 ind[N1];
 #pragma unroll
-            for (int k = 0; k < NE; ++k) ne[k] = 0;
+                for (int n = 0; n < N1; ++n) {
+                    const f32x2 c2 = {cst[0][n], cst[1][n]};
+                    ind[n] = pk_fma_clamp01(c2, H2, nSH);
+                }
+                const f32x2 acc = pk_bitmask<N1>(ind);
+                ne[0] = (uint32_t)acc.x;
+                ne[1] = (uint32_t)acc.y;
+            } else {
 #pragma unroll
-            for (int n = N; n >= 0; --n)
+                for (int k = 0; k < NE; ++k) ne[k] = 0;
 #pragma unroll
-                for (int k = 0; k < NE; ++k)
-                    ne[k] = __builtin_amdgcn_alignbit(ne[k], __float_as_uint(__fsub_rn(S[k], cst[k][n])), 31);
+                for (int n = N; n >= 0; --n)
+#pragma unroll
+                    for (int k = 0; k < NE; ++k)
+                        ne[k] = __builtin_amdgcn_alignbit(ne[k], __float_as_uint(__fsub_rn(S[k], cst[k][n])), 31);
+            }
             uint32_t pk[NE];
 #pragma unroll
             for (int k = 0; k < NE; ++k) {
