@@ -43,6 +43,9 @@ constexpr int kFastThreads = 256;
 #ifndef VBQ_FAST_WAVES
 #define VBQ_FAST_WAVES 4
 #endif
+#ifndef VBQ_SLOW_INLINE
+#define VBQ_SLOW_INLINE __noinline__
+#endif
 #ifndef VBQ_FAST_PKMASK
 #define VBQ_FAST_PKMASK 0     // equality mask by v_sub + v_alignbit (0) or by packed FMAs (1: measured 6 % slower)
 #endif
@@ -163,7 +166,7 @@ __device__ __forceinline__ LevelInfo<N> descend(const float *tb, int n, float z,
 
 // Literal restatement of the reference scan for ONE element and ONE lambda (slow path).
 template <int N>
-__device__ __noinline__ uint32_t exact_rank_scan(const float *tb, float z, float sigma, const float *pen) {
+__device__ VBQ_SLOW_INLINE uint32_t exact_rank_scan(const float *tb, float z, float sigma, const float *pen) {
     const double sg = __ddiv_rn(1.0, (double)sigma);
     uint32_t g = 0;
     float bestL = 0.f, bestR = 0.f;
