@@ -210,6 +210,23 @@ int vbq_bmshj_icdf_step_f32(const float *d_params, const float *d_xi, int64_t n_
 int vbq_bmshj_nll_grad_f32(const float *d_params, const float *d_x_cb, int64_t n_rows, int32_t n_ch,
                            double *d_out /* [n_ch][44] */, void *stream);
 
+/* ----------------------------------------------------------------------------------
+ * Entropy coder for the rank indices.  The reference only ESTIMATES rates
+ * as sum(-log2 freq) (quantizer.py:144,226-228); this turns them into bits.  Static-model rANS
+ * (32-bit state, 16-bit renormalisation, 15 probability bits).
+ *   d_idx    u16 [n_streams][n]   one stream per (lambda, channel): the [L][C][B] planes K1 writes
+ *   d_freq   u16 [n_streams][T]   quantised frequencies, every entry >= 1, each row sums to 2^15
+ *   seg      symbols per independently coded segment (one GPU thread each)
+ *   d_words  u16 [n_streams][nseg][seg+2], nseg = ceil(n/seg): per segment the renormalisation
+ *            words in emission order followed by the final state (low half, high half)
+ *   d_sizes  u32 [n_streams][nseg] number of valid words of every segment
+ * Symbols are coded last-to-first so that decoding runs first-to-last.
+ * ---------------------------------------------------------------------------------- */
+int vbq_rans_encode_u16(const uint16_t *d_idx, int64_t n_streams, int64_t n, int32_t N, int32_t seg,
+                        const uint16_t *d_freq, uint16_t *d_words, uint32_t *d_sizes, void *stream);
+int vbq_rans_decode_u16(const uint16_t *d_words, const uint32_t *d_sizes, int64_t n_streams, int64_t n,
+                        int32_t N, int32_t seg, const uint16_t *d_freq, uint16_t *d_idx, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

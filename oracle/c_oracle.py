@@ -87,3 +87,29 @@ def moments(x, n_ch, layout=0):
     r = lib().vbq_oracle_moments(_p(x), C.c_int64(rows), C.c_int32(n_ch), C.c_int32(layout), _p(out))
     assert r == 0
     return out
+
+
+def rans_encode(idx, freq, seg):
+    """idx u16 [S, n], freq u16 [S, T] -> (words u16 [S, nseg, seg+2], sizes u32 [S, nseg])."""
+    idx = np.ascontiguousarray(idx, np.uint16)
+    freq = np.ascontiguousarray(freq, np.uint16)
+    S, n = idx.shape
+    nseg = (n + seg - 1) // seg
+    words = np.zeros((S, nseg, seg + 2), np.uint16)
+    sizes = np.zeros((S, nseg), np.uint32)
+    r = lib().vbq_oracle_rans_encode(_p(idx), C.c_int64(S), C.c_int64(n), C.c_int32(freq.shape[1]), C.c_int32(seg),
+                                     _p(freq), _p(words), _p(sizes))
+    assert r == 0, r
+    return words, sizes
+
+
+def rans_decode(words, sizes, freq, n, seg):
+    words = np.ascontiguousarray(words, np.uint16)
+    sizes = np.ascontiguousarray(sizes, np.uint32)
+    freq = np.ascontiguousarray(freq, np.uint16)
+    S = freq.shape[0]
+    idx = np.zeros((S, n), np.uint16)
+    r = lib().vbq_oracle_rans_decode(_p(words), _p(sizes), C.c_int64(S), C.c_int64(n), C.c_int32(freq.shape[1]),
+                                     C.c_int32(seg), _p(freq), _p(idx))
+    assert r == 0, r
+    return idx

@@ -184,3 +184,74 @@ int vbq_oracle_max_threads(void) {
     return 1;
 #endif
 }
+
+/* ------------------------------------------------------------------------------------------
+ * rANS segment coder (checker for vbq_amd/csrc/vbq_rans.hip; format documented in include/vbq.h).
+ * 32-bit state, 16-bit renormalisation, 15 probability bits; per segment: emission-order words,
+ * then the final state (low, high).  Textbook rANS (Duda 2013; byte-wise form after F. Giesen's
+ * public-domain ryg_rans), restated for 16-bit words.
+ * ------------------------------------------------------------------------------------------ */
+#define RANS_PB 15
+#define RANS_L (1u << 16)
+
+int vbq_oracle_rans_encode(const uint16_t *idx, int64_t n_streams, int64_t n, int32_t T, int32_t seg,
+                           const uint16_t *freq, uint16_t *words, uint32_t *sizes) {
+    const int64_t nseg = (n + seg - 1) / seg;
+    uint32_t *cum = (uint32_t *)malloc(sizeof(uint32_t) * (T + 1));
+    for (int64_t s = 0; s < n_streams; ++s) {
+        const uint16_t *f = freq + s * T;
+        cum[0] = 0;
+        for (int i = 0; i < T; ++i) cum[i + 1] = cum[i] + f[i];
+        if (cum[T] != (1u << RANS_PB)) { free(cum); return -2; }
+        for (int64_t g = 0; g < nseg; ++g) {
+            const int64_t a = g * seg, b = (a + seg < n) ? a + seg : n;
+            uint16_t *out = words + (s * nseg + g) * (int64_t)(seg + 2);
+            uint32_t x = RANS_L;
+            int k = 0;
+            for (int64_t i = b - 1; i >= a; --i) {
+                const uint32_t sym = idx[s * n + i];
+                const uint32_t fs = f[sym];
+                if (x >= (fs << (32 - RANS_PB))) { out[k++] = (uint16_t)(x & 0xffffu); x >>= 16; }
+                x = ((x / fs) << RANS_PB) + (x % fs) + cum[sym];
+            }
+            out[k++] = (uint16_t)(x & 0xffffu);
+            out[k++] = (uint16_t)(x >> 16);
+            sizes[s * nseg + g] = (uint32_t)k;
+        }
+    }
+    free(cum);
+    return 0;
+}
+
+int vbq_oracle_rans_decode(const uint16_t *words, const uint32_t *sizes, int64_t n_streams, int64_t n, int32_t T,
+                           int32_t seg, const uint16_t *freq, uint16_t *idx) {
+    const int64_t nseg = (n + seg - 1) / seg;
+    uint32_t *cum = (uint32_t *)malloc(sizeof(uint32_t) * (T + 1));
+    uint16_t *lut = (uint16_t *)malloc(sizeof(uint16_t) << RANS_PB);
+    for (int64_t s = 0; s < n_streams; ++s) {
+        const uint16_t *f = freq + s * T;
+        cum[0] = 0;
+        for (int i = 0; i < T; ++i) cum[i + 1] = cum[i] + f[i];
+        if (cum[T] != (1u << RANS_PB)) { free(cum); free(lut); return -2; }
+        for (int i = 0; i < T; ++i)
+            for (uint32_t j = cum[i]; j < cum[i + 1]; ++j) lut[j] = (uint16_t)i;
+        for (int64_t g = 0; g < nseg; ++g) {
+            const int64_t a = g * seg, b = (a + seg < n) ? a + seg : n;
+            const uint16_t *in = words + (s * nseg + g) * (int64_t)(seg + 2);
+            int k = (int)sizes[s * nseg + g];
+            uint32_t x = ((uint32_t)in[k - 1] << 16) | in[k - 2];
+            k -= 2;
+            for (int64_t i = a; i < b; ++i) {
+                const uint32_t slot = x & ((1u << RANS_PB) - 1u);
+                const uint32_t sym = lut[slot];
+                idx[s * n + i] = (uint16_t)sym;
+                x = f[sym] * (x >> RANS_PB) + slot - cum[sym];
+                if (x < RANS_L) x = (x << 16) | in[--k];
+            }
+            if (k != 0 || x != RANS_L) { free(cum); free(lut); return -3; }   /* stream must be consumed exactly */
+        }
+    }
+    free(cum);
+    free(lut);
+    return 0;
+}

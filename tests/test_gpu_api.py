@@ -246,3 +246,21 @@ def test_bmshj_fit_gradient_and_convergence():
     q = np.quantile(data, [0.25, 0.5, 0.75], axis=0)                          # fitted quartiles ~ empirical
     zq = p2.inverse_cdf(np.repeat(np.array([0.25, 0.5, 0.75])[:, None], C, axis=1))
     assert np.allclose(zq, q, atol=0.15)
+
+
+def test_quantizer_bitstream_roundtrip(golden):
+    """encode_batch / decode_batch: the decoded Z_hat equals what compress_batch_channel_latents returns, and
+    the coded size is within 2 % of the reference-style estimate sum(num_bits) on the data the models were fit on."""
+    g, q, _ = _case(golden)
+    lambs = list(2.0 ** np.linspace(-8, 7.5, 6))
+    mu = np.tile(g["mu"], (20, 1)) + np.random.default_rng(0).normal(0, 0.05, (20 * g["mu"].shape[0], 4)).astype(np.float32)
+    sg = np.tile(g["sigma"], (20, 1))
+    q.build_entropy_models_from_latents(mu, sg, lambs, add_n_smoothing=1)
+    words, sizes, cdc = q.encode_batch(mu, sg, lambs, segment=512)
+    Zd, _ = q.compress_batch_channel_latents(mu, sg, lambs)
+    back = q.decode_batch(words, sizes, cdc, mu.shape[0], lambs)
+    for lamb in lambs:
+        assert np.array_equal(back[lamb], Zd[lamb])
+    est = sum(float(np.sum(q.compress_latents(mu[None], 2 * np.log(sg)[None], [lamb])["num_bits"][lamb])) for lamb in lambs[:2])
+    bits2 = cdc.compressed_bits(sizes[: 2 * q.num_channels])
+    assert bits2 <= 1.03 * est + 40 * sizes[: 2 * q.num_channels].numel()

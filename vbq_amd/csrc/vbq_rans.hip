@@ -1,0 +1,128 @@
+// f2: a static-model rANS coder for the rank indices, so that the rates the
+// reference only ESTIMATES as sum(-log2 freq) (quantizer.py:144,226-228) become real bits.
+//
+// Format (ours; the reference has no coder): every (lambda, channel) stream of n indices is cut
+// into segments of `seg` symbols; each segment is an independent rANS stream (32-bit state,
+// 16-bit renormalisation, PB = 15 probability bits, frequencies >= 1 summing to 2^15):
+//     words[0..k-3] = renormalisation words in emission order, words[k-2], words[k-1] = final state
+//     (low, high half), k = size of the segment in 16-bit words (<= seg + 2).
+// Symbols are encoded last-to-first, so the decoder -- starting from the state at the END of the
+// segment and consuming words backwards -- reproduces them first-to-last.  One thread per
+// segment; the 64 segments of a workgroup belong to one stream and share its frequency /
+// cumulative tables in LDS.  oracle/vbq_oracle.c (rans_* functions) is the bit-exact checker.
+#include "vbq_common.h"
+
+namespace vbq {
+namespace {
+
+constexpr int kPB = 15;
+constexpr unsigned kRansL = 1u << 16;
+constexpr int kRansThreads = 64;
+
+__device__ __forceinline__ void stage_tables(const uint16_t *__restrict__ freq, int T, uint16_t *f_l, uint32_t *c_l) {
+    // exclusive prefix sum of <= 2048 frequencies by one wave: each lane owns a contiguous chunk
+    const int lane = threadIdx.x;
+    const int per = (T + kRansThreads - 1) / kRansThreads;
+    unsigned sum = 0;
+    for (int i = lane * per; i < min(T, (lane + 1) * per); ++i) { f_l[i] = freq[i]; sum += freq[i]; }
+    unsigned incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned v = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += v;
+    }
+    unsigned run = incl - sum;
+    for (int i = lane * per; i < min(T, (lane + 1) * per); ++i) { c_l[i] = run; run += f_l[i]; }
+    if (lane == 63) c_l[T] = incl;       // == 2^15 for a valid table
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(kRansThreads)
+k_rans_encode(const uint16_t *__restrict__ idx, long n, int T, int seg, int nseg, const uint16_t *__restrict__ freq,
+              uint16_t *__restrict__ words, uint32_t *__restrict__ sizes) {
+    __shared__ uint16_t f_l[2048];
+    __shared__ uint32_t c_l[2049];
+    const long s = blockIdx.y;                                   // stream
+    stage_tables(freq + s * T, T, f_l, c_l);
+    const int g = blockIdx.x * kRansThreads + threadIdx.x;       // segment within the stream
+    if (g >= nseg) return;
+    const long a = (long)g * seg;
+    const long b = a + seg < n ? a + seg : n;
+    const uint16_t *src = idx + s * n;
+    uint16_t *out = words + (s * nseg + g) * (long)(seg + 2);
+    unsigned x = kRansL;
+    int k = 0;
+    for (long i = b - 1; i >= a; --i) {
+        const unsigned sym = src[i];
+        const unsigned f = f_l[sym], c = c_l[sym];
+        if (x >= (f << (32 - kPB))) { out[k++] = (uint16_t)(x & 0xffffu); x >>= 16; }
+        x = ((x / f) << kPB) + (x % f) + c;
+    }
+    out[k++] = (uint16_t)(x & 0xffffu);
+    out[k++] = (uint16_t)(x >> 16);
+    sizes[s * nseg + g] = (uint32_t)k;
+}
+
+__global__ void __launch_bounds__(kRansThreads)
+k_rans_decode(const uint16_t *__restrict__ words, const uint32_t *__restrict__ sizes, long n, int T, int seg, int nseg,
+              const uint16_t *__restrict__ freq, uint16_t *__restrict__ idx) {
+    __shared__ uint16_t f_l[2048];
+    __shared__ uint32_t c_l[2049];
+    const long s = blockIdx.y;
+    stage_tables(freq + s * T, T, f_l, c_l);
+    const int g = blockIdx.x * kRansThreads + threadIdx.x;
+    if (g >= nseg) return;
+    const long a = (long)g * seg;
+    const long b = a + seg < n ? a + seg : n;
+    const uint16_t *in = words + (s * nseg + g) * (long)(seg + 2);
+    int k = (int)sizes[s * nseg + g];
+    unsigned x = ((unsigned)in[k - 1] << 16) | in[k - 2];
+    k -= 2;
+    uint16_t *dst = idx + s * n;
+    for (long i = a; i < b; ++i) {
+        const unsigned slot = x & ((1u << kPB) - 1u);
+        int lo = 0, hi = T;                                      // last symbol with cum <= slot
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (c_l[mid] <= slot) lo = mid; else hi = mid;
+        }
+        dst[i] = (uint16_t)lo;
+        x = f_l[lo] * (x >> kPB) + slot - c_l[lo];
+        if (x < kRansL) x = (x << 16) | in[--k];
+    }
+}
+
+}  // namespace
+}  // namespace vbq
+
+extern "C" int vbq_rans_encode_u16(const uint16_t *d_idx, int64_t n_streams, int64_t n, int32_t N, int32_t seg,
+                                   const uint16_t *d_freq, uint16_t *d_words, uint32_t *d_sizes, void *stream) {
+    using namespace vbq;
+    VBQ_REQUIRE(n_streams >= 0 && n >= 0 && N >= 1 && N <= 10 && seg >= 1 && seg <= 65533 && n_streams <= 65535,
+                VBQ_ERR_INVALID_ARGUMENT, "vbq_rans_encode_u16: bad sizes n_streams=%lld n=%lld N=%d seg=%d",
+                (long long)n_streams, (long long)n, N, seg);
+    if (n_streams == 0 || n == 0) return VBQ_OK;
+    VBQ_REQUIRE(d_idx && d_freq && d_words && d_sizes, VBQ_ERR_INVALID_ARGUMENT, "vbq_rans_encode_u16: null pointer argument");
+    const int64_t nseg = (n + seg - 1) / seg;
+    hipLaunchKernelGGL(k_rans_encode, dim3((unsigned)((nseg + kRansThreads - 1) / kRansThreads), (unsigned)n_streams),
+                       dim3(kRansThreads), 0, reinterpret_cast<hipStream_t>(stream), d_idx, (long)n, table_size(N), (int)seg,
+                       (int)nseg, d_freq, d_words, d_sizes);
+    VBQ_CHECK_LAUNCH("rans_encode");
+    return VBQ_OK;
+}
+
+extern "C" int vbq_rans_decode_u16(const uint16_t *d_words, const uint32_t *d_sizes, int64_t n_streams, int64_t n,
+                                   int32_t N, int32_t seg, const uint16_t *d_freq, uint16_t *d_idx, void *stream) {
+    using namespace vbq;
+    VBQ_REQUIRE(n_streams >= 0 && n >= 0 && N >= 1 && N <= 10 && seg >= 1 && seg <= 65533 && n_streams <= 65535,
+                VBQ_ERR_INVALID_ARGUMENT, "vbq_rans_decode_u16: bad sizes n_streams=%lld n=%lld N=%d seg=%d",
+                (long long)n_streams, (long long)n, N, seg);
+    if (n_streams == 0 || n == 0) return VBQ_OK;
+    VBQ_REQUIRE(d_idx && d_freq && d_words && d_sizes, VBQ_ERR_INVALID_ARGUMENT, "vbq_rans_decode_u16: null pointer argument");
+    const int64_t nseg = (n + seg - 1) / seg;
+    hipLaunchKernelGGL(k_rans_decode, dim3((unsigned)((nseg + kRansThreads - 1) / kRansThreads), (unsigned)n_streams),
+                       dim3(kRansThreads), 0, reinterpret_cast<hipStream_t>(stream), d_words, d_sizes, (long)n, table_size(N),
+                       (int)seg, (int)nseg, d_freq, d_idx);
+    VBQ_CHECK_LAUNCH("rans_decode");
+    return VBQ_OK;
+}

@@ -237,6 +237,9 @@ class ChannelwisePriorCDFQuantizer:
             counts = merged
         models = _entropy.neg_log2_freq(counts, add_n_smoothing)                    # [L, C, T] f32
         self.entropy_models = {lamb: models[i] for i, lamb in enumerate(lambs)}
+        # kept for the entropy coder (vbq_amd.coder): the integer histograms behind the models
+        self._code_counts = {lamb: counts[i] for i, lamb in enumerate(lambs)}
+        self._add_n_smoothing = add_n_smoothing
         self._dev_cache.pop("entropy", None)
         return None
 
@@ -279,6 +282,35 @@ class ChannelwisePriorCDFQuantizer:
                 output["num_bits_cl"][lamb] = output["raw_num_bits"][lamb]          # :231-232
             output["num_bits"][lamb] = to_latent_shape(num_bits[i])
         return output
+
+    # ------------------------------------------------------------------ real bits
+    def codec(self, lambs, segment=1024):
+        """rANS codec whose frequency tables are the histograms behind entropy_models[lamb]
+        (one table per (lambda, channel)); see vbq_amd.coder."""
+        from .coder import RansCodec, quantize_frequencies
+        if self.entropy_models is None or not hasattr(self, "_code_counts"):
+            raise ValueError("build_entropy_models() first")
+        counts = np.stack([self._code_counts[lamb] for lamb in lambs])              # [L, C, T]
+        freq = quantize_frequencies(counts, add_n_smoothing=self._add_n_smoothing)
+        return RansCodec(freq.reshape(-1, self.quantization_levels), N=self.max_bits_per_coord, segment=segment)
+
+    def encode_batch(self, batch_means, batch_stds, lambs, segment=1024):
+        """Solve + entropy-code: returns (words, sizes, codec); total size = codec.compressed_bits(sizes).
+        Streams are ordered [lambda][channel], each holding the B indices of that channel."""
+        lambs = list(lambs)
+        mu_cb, sg_cb = self._prep(batch_means, batch_stds)
+        idx = self._solve_idx(mu_cb, sg_cb, lambs, self._level_len_dev(lambs))     # [L, C, B]
+        cdc = self.codec(lambs, segment)
+        words, sizes = cdc.encode(idx)
+        return words, sizes, cdc
+
+    def decode_batch(self, words, sizes, codec, n_rows, lambs, return_np=True):
+        """Inverse of encode_batch: dict[lamb] -> Z_hat [B, C]."""
+        lambs = list(lambs)
+        C = self.num_channels
+        idx = codec.decode(words, sizes, n_rows).reshape(len(lambs), C, n_rows)
+        zhat = ops.gather(idx, self._sorted_dev(), C, N=self.max_bits_per_coord, layout="cb", out_layout="bc")
+        return {lamb: (zhat[i].cpu().numpy() if return_np else zhat[i]) for i, lamb in enumerate(lambs)}
 
     def compress(self, X, vae, lambs, clip=True):
         lambs = list(lambs)
