@@ -54,10 +54,17 @@ def test_quantizer_tables_state_and_pickle(golden):
     assert np.array_equal(q.code_points_by_channel, orc.by_channel)
     assert np.array_equal(q._search_grids, orc.grids)
     assert len(q.code_points_by_bits) == C and len(q.code_points_by_bits[0][7]) == 128
-    q.raw_code_length_entropy_models = {0.5: np.zeros((C, N + 1), np.float32)}
+    q.raw_code_length_entropy_models = {0.5: np.zeros((C, N + 1), np.float32), 0.25: np.ones((C, N + 1), np.float32)}
     q.entropy_models = {0.5: np.zeros((C, 2047), np.float32), 0.25: np.zeros((C, 2047), np.float32)}
     q2 = pickle.loads(pickle.dumps(q))                      # post_process.py:106-107,163-164
     assert q2.lambs == [0.25, 0.5] and np.array_equal(q2.all_code_points, q.all_code_points)
+    import os, tempfile
+    with tempfile.TemporaryDirectory() as td:                # the .npz format next to pickle
+        q.save(os.path.join(td, "q.npz"))
+        q3 = ChannelwisePriorCDFQuantizer.load(os.path.join(td, "q.npz"))
+    assert q3.lambs == [0.25, 0.5] and np.array_equal(q3.all_code_points, q.all_code_points)
+    assert np.array_equal(q3._search_grids, q._search_grids) and np.array_equal(q3.entropy_models[0.5], q.entropy_models[0.5])
+    assert np.array_equal(q3.raw_code_length_entropy_models[0.5], q.raw_code_length_entropy_models[0.5])
 
     class Bad:
         def inverse_cdf(self, xi):

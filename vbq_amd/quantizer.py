@@ -73,6 +73,49 @@ class ChannelwisePriorCDFQuantizer:
         self.__dict__.update(st)
         self._dev_cache = {}
 
+    # ------------------------------------------------------------------ on-disk format
+    def save(self, path):
+        """Portable alternative to the reference's pickle (post_process.py:106-107): one .npz holding the
+        code-point table, the two entropy-model dicts (keys = lambdas as float64) and the histograms."""
+        if not hasattr(self, "all_code_points"):
+            raise ValueError("nothing to save: build_code_points() first")
+        d = dict(format=np.array("vbq_amd.quantizer/1"), num_channels=self.num_channels,
+                 max_bits_per_coord=self.max_bits_per_coord, all_code_points=self.all_code_points)
+        if self.entropy_models:
+            lambs = self.lambs
+            d["lambdas"] = np.array([float(l) for l in lambs], dtype=np.float64)
+            d["entropy_models"] = np.stack([self.entropy_models[l] for l in lambs])
+            if self.raw_code_length_entropy_models:
+                d["raw_code_length_entropy_models"] = np.stack([self.raw_code_length_entropy_models[l] for l in lambs])
+            if hasattr(self, "_code_counts"):
+                d["code_counts"] = np.stack([self._code_counts[l] for l in lambs])
+                d["add_n_smoothing"] = np.array(self._add_n_smoothing)
+        np.savez_compressed(path, **d)
+
+    @classmethod
+    def load(cls, path, device=None):
+        z = np.load(path, allow_pickle=False)
+        if str(z["format"]) != "vbq_amd.quantizer/1":
+            raise ValueError(f"{path}: unknown format {z['format']}")
+        q = cls(int(z["num_channels"]), int(z["max_bits_per_coord"]), device=device)
+
+        class _Table:
+            def __init__(self, pts):
+                self.pts = pts
+
+            def inverse_cdf(self, xi):
+                return self.pts
+        q.build_code_points(_Table(np.ascontiguousarray(z["all_code_points"].T)))
+        if "lambdas" in z:
+            lambs = [float(v) for v in z["lambdas"]]
+            q.entropy_models = {l: z["entropy_models"][i] for i, l in enumerate(lambs)}
+            if "raw_code_length_entropy_models" in z:
+                q.raw_code_length_entropy_models = {l: z["raw_code_length_entropy_models"][i] for i, l in enumerate(lambs)}
+            if "code_counts" in z:
+                q._code_counts = {l: z["code_counts"][i] for i, l in enumerate(lambs)}
+                q._add_n_smoothing = z["add_n_smoothing"].item()
+        return q
+
     @property
     def device(self):
         if self._device is None:
