@@ -40,7 +40,9 @@ WORKLOADS = {
     "kodak24_c256": (36864, 256, "Kodak-24 latents of bls2017 (num_filters=256): [36864 x 256] f32"),
     "kodak24_c32": (36864, 32, "Kodak-24 latents of bls2017 (default num_filters=32): [36864 x 32] f32"),
     "embeddings_1e7": (10_000_000, 1, "word embeddings 100000 x 100, one Gaussian code book"),
-    "synthetic_1e8": (100_000_000, 1, "synthetic 1e8-element tensor, one code book"),
+    "embeddings_4e5x300": (120_000_000, 1, "word embeddings 4e5 x 300 (BASELINE.json configs[2]), one Gaussian code book"),
+    "synthetic_1e8": (100_000_000, 1, "synthetic 1e8-element tensor, one code book (configs[3])"),
+    "shard_1.25e8": (125_000_000, 1, "one rank's 1.25e8-element shard of the 1e9-element tensor (configs[4])"),
 }
 
 
