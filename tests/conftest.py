@@ -20,3 +20,12 @@ def golden():
     def load(name):
         return np.load(os.path.join(GOLDEN, name))
     return load
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _native_built():
+    """Test infrastructure: make sure the in-tree HIP extension and the C oracle are built and current
+    (hipcc cross-compiles gfx950 without a GPU).  The product itself never builds on import."""
+    from vbq_amd import build
+    build.build_hip()
+    build.build_oracle()
