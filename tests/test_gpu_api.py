@@ -224,7 +224,7 @@ def test_bmshj_fit_gradient_and_convergence():
            [torch.tensor(f, dtype=torch.float64, requires_grad=True) for f in p.factors])
     ref = _torch_nll(raw, torch.tensor(data, dtype=torch.float64))
     ref.backward()
-    assert loss == pytest.approx(float(ref), rel=2e-5)
+    assert loss == pytest.approx(float(ref.detach()), rel=2e-5)
     want = []
     for i in range(4):
         want += [raw[0][i].grad.numpy(), raw[1][i].grad.numpy()] + ([raw[2][i].grad.numpy()] if i < 3 else [])
@@ -264,3 +264,37 @@ def test_quantizer_bitstream_roundtrip(golden):
     est = sum(float(np.sum(q.compress_latents(mu[None], 2 * np.log(sg)[None], [lamb])["num_bits"][lamb])) for lamb in lambs[:2])
     bits2 = cdc.compressed_bits(sizes[: 2 * q.num_channels])
     assert bits2 <= 1.03 * est + 40 * sizes[: 2 * q.num_channels].numel()
+
+
+def test_quantizer_with_repeated_code_points():
+    """Tables whose f32 cast repeats values (SURVEY 7.2 hard part 4): qidx is the FIRST sorted position of a
+    repeated value (quantizer.py:135), so the histograms / entropy models merge the duplicates exactly as the
+    reference's searchsorted does."""
+    from scipy.stats import norm
+    from vbq_amd import ChannelwisePriorCDFQuantizer
+
+    class Coarse:
+        def inverse_cdf(self, xi):
+            return np.round(norm.ppf(xi) * np.array([24.0, 64.0])) / np.array([24.0, 64.0])
+    C = 2
+    q = ChannelwisePriorCDFQuantizer(C, N)
+    q.build_code_points(Coarse())
+    assert not q._strict
+    orc = O.ChannelwiseOracle(C, N)
+    orc.build_code_points(Coarse().inverse_cdf)
+    rng = np.random.default_rng(21)
+    mu = rng.normal(0, 1.1, (4000, C)).astype(np.float32)
+    sg = np.exp(rng.normal(-2, 0.7, (4000, C))).astype(np.float32)
+    lambs = [0.01, 0.3, 4.0]
+    q.build_entropy_models_from_latents(mu, sg, lambs, add_n_smoothing=1)
+    orc.build_entropy_models(mu, sg, [np.float32(l) for l in lambs], add_n_smoothing=1)
+    for l in lambs:
+        assert np.array_equal(q.raw_code_length_entropy_models[l], orc.raw_models[np.float32(l)])
+        assert np.array_equal(q.entropy_models[l], orc.entropy_models[np.float32(l)])
+    out = q.compress_latents(mu[None], (2 * np.log(sg))[None], lambs)
+    stds = (torch.exp(torch.from_numpy(2 * np.log(sg)).cuda()) ** 0.5).cpu().numpy()
+    if np.array_equal(stds, sg):
+        ref = orc.compress_latents(mu, sg, [np.float32(l) for l in lambs])
+        for l in lambs:
+            assert np.array_equal(out["Z_hat"][l][0], ref["Z_hat"][np.float32(l)])
+            assert np.array_equal(out["num_bits"][l][0], ref["num_bits"][np.float32(l)])
