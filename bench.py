@@ -253,6 +253,10 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": k1_ms,
                          "latents_per_s_kernel_only": E * L / (k1_ms * 1e-3)},
             "stages_ms": {"k1_solve": k1_ms, "k2_histogram": k2_ms},
+            "roofline_k2_histogram": (None if k2_ms is None else
+                                      {"bound": "hbm", "kernel": "k_hist_flat", "achieved": 2.0 * L * E / (k2_ms * 1e-3) / 1e9,
+                                       "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": 2.0 * L * E / (k2_ms * 1e-3) / HBM_PEAK,
+                                       "algorithmic_bytes_per_launch": 2 * L * E, "avg_launch_ms": k2_ms}),
         }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         ll_h = level_len.cpu().numpy() if level_len is not None else None
