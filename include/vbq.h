@@ -227,6 +227,22 @@ int vbq_rans_encode_u16(const uint16_t *d_idx, int64_t n_streams, int64_t n, int
 int vbq_rans_decode_u16(const uint16_t *d_words, const uint32_t *d_sizes, int64_t n_streams, int64_t n,
                         int32_t N, int32_t seg, const uint16_t *d_freq, uint16_t *d_idx, void *stream);
 
+/* ----------------------------------------------------------------------------------
+ * Comparison quantizers (img-compression/quantizer.py:259-333).
+ *   vbq_uniform_quantize_f32  I = clip(floor((x - min) / delta), 0, levels-1) in f32 (:280,295),
+ *                             value = offset + delta * I (:297); I is returned as f32 like the
+ *                             reference does.  UniformQuantizer.quantize and the index pass of .fit.
+ *   vbq_nearest_code_f64      scipy.cluster.vq.vq(samples, code_points) for 1-D data (:329): f64
+ *                             squared distance, first minimum in code-book order; value = the code.
+ * Any output may be NULL; d_counts (int64 [levels] / [n_codes]) is ADDED to when given: the
+ * np.bincount of :281 / :314.
+ * ---------------------------------------------------------------------------------- */
+int vbq_uniform_quantize_f32(const float *d_x, int64_t n, float min, float delta, float offset,
+                             int32_t levels, float *d_out_index, float *d_out_value, int64_t *d_counts,
+                             void *stream);
+int vbq_nearest_code_f64(const float *d_x, int64_t n, const double *d_codes, int32_t n_codes,
+                         int32_t *d_out_index, double *d_out_value, int64_t *d_counts, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -573,3 +573,38 @@ def lagrangian(mu, sigma, z_hat, bits, lamb) -> float:
     sigma = sigma.astype(np.float64)
     d = ((z_hat.astype(np.float64) - mu) / sigma) ** 2 * 0.5
     return float(d.sum() + float(lamb) * bits.astype(np.float64).sum())
+
+
+# ---------------------------------------------------------------------------------------------
+# f3: comparison quantizers (img-compression/quantizer.py:259-333), NumPy restatement.
+# ---------------------------------------------------------------------------------------------
+def uniform_fit(samples, levels, add_n_smoothing=1):
+    """UniformQuantizer.fit (quantizer.py:266-290): grid from the sample range, empirical code lengths."""
+    s = np.asarray(samples)
+    mn, mx = np.min(s), np.max(s)
+    delta = (mx - mn) / levels
+    offset = mn + delta / 2
+    code_points = offset + delta * np.arange(levels)
+    I = np.clip(np.floor((s - mn) / delta), 0, levels - 1)
+    counts = np.bincount(I.astype(np.int32), minlength=levels)
+    if np.any(counts == 0):
+        counts = counts + add_n_smoothing
+    return dict(min=mn, delta=delta, code_points=code_points, code_lengths=-np.log2(counts / len(s)))
+
+
+def uniform_quantize(samples, fit):
+    """UniformQuantizer.quantize (quantizer.py:292-300): (quantized f32, I f32, num_bits f64)."""
+    s = np.asarray(samples)
+    levels = len(fit["code_points"])
+    I = np.clip(np.floor((s - fit["min"]) / fit["delta"]), 0, levels - 1)
+    offset = fit["min"] + fit["delta"] / 2
+    return offset + fit["delta"] * I, I, np.take(fit["code_lengths"], I.astype(np.int32))
+
+
+def nearest_code(samples, code_points):
+    """scipy.cluster.vq.vq for 1-D data (quantizer.py:329): f64 squared distance, first minimum."""
+    s = np.asarray(samples, dtype=np.float64).reshape(-1, 1)
+    c = np.asarray(code_points, dtype=np.float64).reshape(1, -1)
+    d = s - c
+    I = np.argmin(d * d, axis=1).astype(np.int32)
+    return np.take(np.asarray(code_points, dtype=np.float64), I), I

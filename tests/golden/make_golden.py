@@ -193,9 +193,39 @@ def g7():
          optima=np.stack(outs), entropy=np.array(ents))
 
 
+# ---------------------------------------------------------------- G9 (baseline quantizers)
+def g9():
+    """UniformQuantizer / KmeansQuantizer.quantize (quantizer.py:259-333).  quantizer.py imports tensorflow at
+    module level, so the two NumPy-only classes are exec'd from their source lines (nothing is copied into
+    the repo: only their outputs are saved)."""
+    src = open(os.path.join(REF, "img-compression", "quantizer.py")).read().split("\n")
+    start = next(i for i, l in enumerate(src) if l.startswith("class UniformQuantizer"))
+    stop = next(i for i, l in enumerate(src) if l.startswith("class ChannelwiseSimpleQuantizer:"))
+    ns = {"np": np}
+    exec("\n".join(src[start:stop]), ns)
+    rng = np.random.default_rng(109)
+    x = rng.normal(0.2, 1.3, 5000).astype(np.float32)
+    out = {"x": x}
+    for K in (4, 16, 61):
+        u = ns["UniformQuantizer"](K)
+        u.fit(x, add_n_smoothing=1)      # int: the float default cannot be added in place to the int64 counts (:282)
+        qz, I, nb = u.quantize(x)
+        out[f"u{K}_min"], out[f"u{K}_delta"] = np.asarray(u.min), np.asarray(u.delta)
+        out[f"u{K}_code_points"], out[f"u{K}_code_lengths"] = u.code_points, u.code_lengths
+        out[f"u{K}_q"], out[f"u{K}_I"], out[f"u{K}_bits"] = qz, I, nb
+    centers = np.sort(rng.normal(0, 1.5, 12)).astype(np.float64)[rng.permutation(12)]      # unsorted, as sklearn returns
+    k = ns["KmeansQuantizer"](12)
+    k.code_points = centers
+    k.code_lengths = -np.log2(np.full(12, 1 / 12.0))
+    qz, I, nb = k.quantize(x)
+    out["k_centers"], out["k_q"], out["k_I"] = centers, qz, I
+    save("g9_baselines.npz", **out)
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "reference tree not found; this script only runs in the build container"
     g1_g2_g3()
     g4()
     g5_g6_g8()
     g7()
+    g9()

@@ -185,3 +185,20 @@ def test_cfg1_single_image_plumbing():
     assert 0.5 < bpl < 8.0
     d = O.lagrangian(mu, sg, z, out["raw_num_bits"][lam[0]], 0.5)
     assert np.isfinite(d) and d > 0
+
+
+def test_g9_baseline_quantizers(golden):
+    """f3: oracle restatement of UniformQuantizer / KmeansQuantizer.quantize vs the reference classes."""
+    from oracle import vbq_oracle as o
+    g = golden("g9_baselines.npz")
+    x = g["x"]
+    for K in (4, 16, 61):
+        f = o.uniform_fit(x, K, 1)
+        assert f["min"] == g[f"u{K}_min"] and f["delta"] == g[f"u{K}_delta"]
+        assert np.array_equal(f["code_points"], g[f"u{K}_code_points"])
+        assert np.array_equal(f["code_lengths"], g[f"u{K}_code_lengths"])
+        q, I, nb = o.uniform_quantize(x, f)
+        assert q.dtype == g[f"u{K}_q"].dtype and np.array_equal(q, g[f"u{K}_q"])
+        assert np.array_equal(I, g[f"u{K}_I"]) and np.array_equal(nb, g[f"u{K}_bits"])
+    q, I = o.nearest_code(x, g["k_centers"])
+    assert np.array_equal(q, g["k_q"]) and np.array_equal(I, g["k_I"])
