@@ -10,7 +10,7 @@
 //  * the two candidates of a bit level share their penalty, and rounding is monotone, so
 //    min(cost(L_n), cost(R_n)) = fl(min(dL, dR) + pen_n).  Phase A (once per element) keeps
 //    du_n = min(dL_n, dR_n) in registers (11 VGPRs) and parks one packed word per level in an
-//    LDS scratch column:  [ 0 | gap code:10 (float bits 30..21) | 0:10 | rank of the better side:11 ].
+//    LDS scratch column:  [ top 11 bits of fl(dR - dL), sign flipped | 0:10 | rank of the better side:11 ].
 //  * phase B (per lambda): 11 adds of the penalties, a v_min3 tree for the best cost S, then
 //    sign(S - c_n) shifted into a bit mask (v_alignbit) -- two ops per level, no VCC traffic --
 //    gives the set of levels that attain S.  One LDS read fetches the packed word of the first.
@@ -24,9 +24,9 @@
 //      (a) more than one level attains S (a cross-level tie: an L of a deeper level beats an R
 //          of a shallower one);
 //      (b) the better side of the winning level is R and the two sides are so close that
-//          fl(dL + pen) may round onto fl(dR + pen), which would hand the win to L.  The 10-bit
-//          gap code is a lower bound of |dL - dR| (all ones when L is the better side); the flag
-//          is raised when it is <= 2^-21 * S.
+//          fl(dL + pen) may round onto fl(dR + pen), which would hand the win to L.  The packed
+//          gap is a lower bound of dL - dR (>= 2^31 as an unsigned word when L is the better side);
+//          the flag is raised when it is below 2^-20 * S (tested as packed word <= bits(2^-19 * S)).
 //    A wave with any flagged lane re-solves those lanes for that lambda with the literal
 //    21-candidate scan (exact_rank_scan).  Both events have probability ~1e-6 per solve.
 #include <stdlib.h>
@@ -262,21 +262,45 @@ k_quant_fast(const float *__restrict__ mu, const float *__restrict__ sg, long n_
             g[k] = 0;
             rinv[k] = __ddiv_rn(1.0, (double)s4[k]);
         }
+        // Slot arithmetic in BYTES (g4 = 4 * slot) so that every LDS address is a register plus an immediate.
+        // With G = (number of level-n points below z) = j + [p_n[j] < z], the reference's interval is
+        // L = max(G - 1, 0), R = min(G, 2^n - 1) (quantizer.py:75-76 on the padded grid), except on the deepest
+        // level, whose grid has no padding: there L stays at 2^N - 2 when z is above the last point.
+        const char *tbb = reinterpret_cast<const char *>(tb);
 #pragma unroll
         for (int n = 0; n <= N; ++n) {
+            constexpr int kWordMask = 0xffe00000u;
+            const int off4 = 4 * ((1 << n) - 1);
+            const int top4 = 4 * ((1 << n) - 1);                 // byte offset of the last slot of the level
 #pragma unroll
             for (int k = 0; k < NE; ++k) {
-                const LevelInfo<N> li = descend<N>(tb, n, m4[k], rinv[k], g[k]);
-                const uint32_t rkL = ((2 * li.posL + 1) << (N - n)) - 1;
-                const uint32_t rkR = ((2 * li.posR + 1) << (N - n)) - 1;
-                const bool r_better = li.dR < li.dL;           // strict: on equal costs L keeps the level
-                du[k][n] = r_better ? li.dR : li.dL;
-                const uint32_t better = r_better ? rkR : rkL;
-                // lower bound of dL - dR in 10 bits (top bits of the float, minus one code); all
-                // ones when L is the better side: then no rounding can take the level from it
-                const uint32_t gb = __float_as_uint(__fsub_rn(li.dL, li.dR)) >> 21;
-                const uint32_t gcode = r_better ? (gb > 0 ? gb - 1 : 0) : 0x3ffu;
-                scratch[(n * NE + k) * kFastThreads + threadIdx.x] = (gcode << 21) | better;
+                const float pj = *reinterpret_cast<const float *>(tbb + off4 + g[k]);
+                const bool below = pj < m4[k];
+                float dL, dR;
+                uint32_t lo4, hi4;
+                if (n == 0) {
+                    dL = dR = dist_cost(pj, m4[k], rinv[k]);
+                    lo4 = hi4 = 0;
+                } else {
+                    const uint32_t G4 = g[k] + (below ? 4u : 0u);
+                    int lo = (int)G4 - 4;
+                    lo = lo < 0 ? 0 : lo;
+                    if (n == N) lo = lo > top4 - 4 ? top4 - 4 : lo;
+                    lo4 = (uint32_t)lo;
+                    hi4 = G4 > (uint32_t)top4 ? (uint32_t)top4 : G4;
+                    dL = dist_cost(*reinterpret_cast<const float *>(tbb + off4 + lo4), m4[k], rinv[k]);
+                    dR = dist_cost(*reinterpret_cast<const float *>(tbb + off4 + hi4), m4[k], rinv[k]);
+                }
+                const bool r_better = dR < dL;                  // strict: on equal costs L keeps the level
+                du[k][n] = fminf(dL, dR);
+                const uint32_t b4 = r_better ? hi4 : lo4;
+                // rank index ((2 pos + 1) << (N - n)) - 1 of the better side, from 4 * pos
+                const uint32_t better = n < N ? (b4 << (N - n - 1)) + ((1u << (N - n)) - 1u) : (b4 >> 1);
+                // top 11 bits of fl(dR - dL) with the sign flipped: a (truncated, hence lower) bound of dL - dR
+                // when R is the better side, and >= 2^31 -- never "close" -- when L is (dR - dL >= +0)
+                const uint32_t gap = __float_as_uint(__fsub_rn(dR, dL)) ^ 0x80000000u;
+                scratch[(n * NE + k) * kFastThreads + threadIdx.x] = (gap & kWordMask) | better;
+                g[k] = 2 * g[k] + (below ? 4u : 0u);
             }
         }
 
@@ -287,8 +311,6 @@ k_quant_fast(const float *__restrict__ mu, const float *__restrict__ sg, long n_
 #pragma unroll
             for (int n = 0; n < N1; ++n) p[n] = pp[n];
             uint32_t rank[NE];
-            bool flagged[NE];
-            bool any_flag = false;
             // The NE solves are written level-by-level across elements so that neighbouring
             // instructions are independent (one element's chain alone issues ~1 op / 8 cycles).
             float cst[NE][N1];
@@ -384,20 +406,30 @@ k_quant_fast(const float *__restrict__ mu, const float *__restrict__ sg, long n_
                 const int n1 = __builtin_ctz(~ne[k]);           // first (shallowest) level that attains S
                 pk[k] = scratch[(n1 * NE + k) * kFastThreads + threadIdx.x];
             }
+            // Flags are kept as 64-bit lane masks in SGPRs (v_cmp writes them there): OR-ing them and testing
+            // for "any" is scalar work, no VALU op.  LLVM icmp predicates: 33 = ne, 37 = ule.
+            uint64_t fm[NE];
 #pragma unroll
             for (int k = 0; k < NE; ++k) {
-                const bool multi = __popc(ne[k]) != N;          // more than one level attains S
-                // gap code sits at the float's own bit positions [30:21]: compare bit patterns directly
-                const uint32_t thr = __float_as_uint(__fmul_rn(S[k], 4.76837158203125e-07f));
-                const bool lr_close = (pk[k] & 0x7fe00000u) <= thr;
+                // more than one level attains S
+                const uint64_t multi = __builtin_amdgcn_uicmp((uint32_t)__popc(ne[k]), (uint32_t)N, 33);
+                // The gap sits at the float's own bit positions [31:21]: compare bit patterns directly.
+                // fl(dL + pen) can meet fl(dR + pen) only if dL - dR <= ulp(S) <= 2^-22 S.  The test
+                // (word & 0xffe00000) <= bits(2^-20 S) is implied by word <= bits(2^-19 S) without the mask
+                // (doubling a float adds 2^23 to its bit pattern, more than the 21 low bits can hold).
+                const uint32_t thr = __float_as_uint(__fmul_rn(S[k], 1.9073486328125e-06f));
+                const uint64_t lr_close = __builtin_amdgcn_uicmp(pk[k], thr, 37);
                 rank[k] = pk[k] & 0x7ffu;
-                flagged[k] = ((multi || lr_close) && !never_flag) || force_slow;
-                any_flag = any_flag || flagged[k];
+                fm[k] = never_flag ? 0ull : (force_slow ? ~0ull : (multi | lr_close));
             }
-            if (__any(any_flag)) {
+            uint64_t any_flag = 0;
+#pragma unroll
+            for (int k = 0; k < NE; ++k) any_flag |= fm[k];
+            if (any_flag != 0) {
+                const uint32_t lane = __lane_id();
 #pragma unroll
                 for (int k = 0; k < NE; ++k)
-                    if (flagged[k]) rank[k] = exact_rank_scan<N>(tb, m4[k], s4[k], pp);
+                    if ((fm[k] >> lane) & 1ull) rank[k] = exact_rank_scan<N>(tb, m4[k], s4[k], pp);
             }
             const long o = (long)l * E + base + i0;
             float zh[NE], bt[NE];
