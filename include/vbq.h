@@ -243,6 +243,20 @@ int vbq_uniform_quantize_f32(const float *d_x, int64_t n, float min, float delta
 int vbq_nearest_code_f64(const float *d_x, int64_t n, const double *d_codes, int32_t n_codes,
                          int32_t *d_out_index, double *d_out_value, int64_t *d_counts, void *stream);
 
+/* ----------------------------------------------------------------------------------
+ * Analogy evaluator (compress-trained-word-embeddings.ipynb cell 14, ipynb:199-209):
+ * prediction_ranks(emb) for Q questions (a, b, c, d) given as int32 [Q][4] word ids.
+ *   normed = emb / (1e-8 + |emb|_2);  pred = normed[b] - normed[a] + normed[c];
+ *   rank   = V - #{v : pred . normed[v] < pred . normed[d]} - 1        (int64 [Q])
+ * One fused f32 MFMA GEMM [Q x K] x [K x V]; the score matrix never reaches HBM.  Scores are fma
+ * chains over ascending k (the oracle restates exactly that); NumPy's BLAS order differs in the last
+ * bits, which can move a rank only where another word's score is within rounding of the ground truth.
+ * Workspace: vbq_analogy_ranks_workspace_bytes(V, K, Q) bytes of device memory.
+ * ---------------------------------------------------------------------------------- */
+size_t vbq_analogy_ranks_workspace_bytes(int64_t V, int32_t K, int64_t Q);
+int vbq_analogy_ranks_f32(const float *d_emb, int64_t V, int32_t K, const int32_t *d_analogies, int64_t Q,
+                          int64_t *d_out_ranks, void *d_workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -113,3 +113,14 @@ def rans_decode(words, sizes, freq, n, seg):
                                      C.c_int32(seg), _p(freq), _p(idx))
     assert r == 0, r
     return idx
+
+
+def analogy_ranks(emb, analogies, threads=1):
+    """prediction_ranks with the GPU path's documented arithmetic (fma chain in k order)."""
+    e = np.ascontiguousarray(emb, np.float32)
+    an = np.ascontiguousarray(analogies, np.int32)
+    out = np.empty(an.shape[0], np.int64)
+    r = lib().vbq_oracle_analogy_ranks(_p(e), C.c_int64(e.shape[0]), C.c_int32(e.shape[1]), _p(an), C.c_int64(an.shape[0]),
+                                       _p(out), C.c_int32(threads))
+    assert r == 0
+    return out

@@ -255,3 +255,44 @@ int vbq_oracle_rans_decode(const uint16_t *words, const uint32_t *sizes, int64_t
     free(lut);
     return 0;
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * f4: prediction_ranks (compress-trained-word-embeddings.ipynb cell 14, ipynb:199-209), restated with
+ * the arithmetic the GPU path documents: f32 row norms summed in index order, IEEE division,
+ * (normed[b] - normed[a]) + normed[c], scores as an fma chain over ascending k, strict '<'.
+ * NumPy/BLAS (the reference) rounds the dot products in a different order; tests compare with it
+ * through a near-tie tolerance and with this function bit for bit.
+ * --------------------------------------------------------------------------------------------- */
+int vbq_oracle_analogy_ranks(const float *emb, int64_t V, int32_t K, const int32_t *an, int64_t Q, int64_t *ranks,
+                             int32_t threads) {
+    float *nrm = (float *)malloc(sizeof(float) * (size_t)V * K);
+    if (!nrm) return -1;
+#pragma omp parallel for num_threads(threads > 0 ? threads : 1)
+    for (int64_t v = 0; v < V; ++v) {
+        float s = 0.0f;
+        for (int k = 0; k < K; ++k) s = s + emb[v * K + k] * emb[v * K + k];
+        const float den = 1e-8f + sqrtf(s);
+        for (int k = 0; k < K; ++k) nrm[v * K + k] = emb[v * K + k] / den;
+    }
+#pragma omp parallel for num_threads(threads > 0 ? threads : 1)
+    for (int64_t i = 0; i < Q; ++i) {
+        const float *a = nrm + (int64_t)an[4 * i] * K, *b = nrm + (int64_t)an[4 * i + 1] * K;
+        const float *c = nrm + (int64_t)an[4 * i + 2] * K, *d = nrm + (int64_t)an[4 * i + 3] * K;
+        float *p = (float *)malloc(sizeof(float) * (size_t)K);
+        float gt = 0.0f;
+        for (int k = 0; k < K; ++k) {
+            p[k] = (b[k] - a[k]) + c[k];
+            gt = fmaf(p[k], d[k], gt);
+        }
+        int64_t below = 0;
+        for (int64_t v = 0; v < V; ++v) {
+            float s = 0.0f;
+            for (int k = 0; k < K; ++k) s = fmaf(p[k], nrm[v * K + k], s);
+            below += s < gt;
+        }
+        ranks[i] = V - below - 1;
+        free(p);
+    }
+    free(nrm);
+    return 0;
+}

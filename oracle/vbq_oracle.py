@@ -608,3 +608,32 @@ def nearest_code(samples, code_points):
     d = s - c
     I = np.argmin(d * d, axis=1).astype(np.int32)
     return np.take(np.asarray(code_points, dtype=np.float64), I), I
+
+
+# ---------------------------------------------------------------------------------------------
+# f4: downstream evaluators of the word-embedding notebook (ipynb cells 14, 30, 36), NumPy restatement.
+# ---------------------------------------------------------------------------------------------
+def prediction_ranks(emb, analogies_id, dtype=np.float64):
+    """ipynb cell 14 (ipynb:199-209) in `dtype` arithmetic; returns (ranks, near) where near[i] counts the
+    words whose score is within 1e-5 of the ground truth -- the slack any f32 evaluation order has."""
+    emb = np.asarray(emb, dtype)
+    an = np.asarray(analogies_id)
+    normed = emb / (1e-8 + np.sqrt(np.sum(emb ** 2, axis=1, keepdims=True)))
+    pred = normed[an[:, 1]] - normed[an[:, 0]] + normed[an[:, 2]]
+    scores = pred.dot(normed.T)
+    gt = scores[np.arange(len(an)), an[:, 3]]
+    ranks = scores.shape[1] - np.sum(scores < gt[:, None], axis=1) - 1
+    near = np.sum(np.abs(scores - gt[:, None]) < 1e-5, axis=1) - 1
+    return ranks, near
+
+
+def analogy_metrics(ranks):
+    """ipynb cell 30: (mrr, acc, hits10)."""
+    ranks = np.asarray(ranks)
+    return np.average(1 / (1 + ranks)), np.sum(ranks == 0) / len(ranks), np.sum(ranks < 10) / len(ranks)
+
+
+def quantize_coordinates(means, quantization_max):
+    """ipynb cell 36: uniform rounding baseline."""
+    scale = (quantization_max + 0.5) / np.abs(means).max()
+    return np.round(np.clip(scale * means, -quantization_max, quantization_max))

@@ -222,6 +222,33 @@ def g9():
     save("g9_baselines.npz", **out)
 
 
+# ---------------------------------------------------------------- G10 (analogy evaluator)
+def g10():
+    """prediction_ranks and quantize_coordinates (notebook cells 14, 36) exec'd from the JSON on a seeded
+    synthetic embedding with planted analogies."""
+    nb_path = os.path.join(REF, "word-embeddings", "compress-trained-word-embeddings.ipynb")
+    cells = json.load(open(nb_path))["cells"]
+    src = {i: "".join(c["source"]) for i, c in enumerate(cells) if c["cell_type"] == "code"}
+    assert "def prediction_ranks" in src[14] and "def quantize_coordinates" in src[36]
+    rng = np.random.default_rng(110)
+    V, K, Q = 2000, 50, 500
+    emb = rng.normal(0, 1, (V, K)).astype(np.float32)
+    an = rng.integers(0, V, (Q, 4))
+    # plant structure so that ranks are not all ~V/2: d = b - a + c + noise for the first 400 questions
+    for i in range(300):
+        a, b, c, d = an[i]
+        emb[d] = emb[b] - emb[a] + emb[c] + rng.normal(0, 0.6 + 0.005 * i, K).astype(np.float32)
+    ns = dict(np=np, analogies_id=an)
+    exec(src[14], ns)
+    exec(src[36], ns)
+    ranks = ns["prediction_ranks"](emb)
+    qz = {str(q): ns["quantize_coordinates"](emb, q) for q in (7, 1023)}
+    assert all(v.dtype == np.float32 and np.array_equal(v, v.astype(np.int16)) for v in qz.values())
+    ranks_q7 = ns["prediction_ranks"](qz["7"])
+    save("g10_analogy.npz", emb=emb, analogies=an.astype(np.int32), ranks=ranks.astype(np.int64),
+         ranks_q7=ranks_q7.astype(np.int64), **{f"quantized_{k}": v.astype(np.int16) for k, v in qz.items()})      # integer-valued f32, stored as int16
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "reference tree not found; this script only runs in the build container"
     g1_g2_g3()
@@ -229,3 +256,4 @@ if __name__ == "__main__":
     g5_g6_g8()
     g7()
     g9()
+    g10()

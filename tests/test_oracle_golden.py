@@ -202,3 +202,22 @@ def test_g9_baseline_quantizers(golden):
         assert np.array_equal(I, g[f"u{K}_I"]) and np.array_equal(nb, g[f"u{K}_bits"])
     q, I = o.nearest_code(x, g["k_centers"])
     assert np.array_equal(q, g["k_q"]) and np.array_equal(I, g["k_I"])
+
+
+def test_g10_prediction_ranks(golden):
+    """f4: the f64 restatement and the C checker (fma chain in k order, what the GPU path computes) against the
+    notebook's prediction_ranks run on NumPy/BLAS f32: equal except where another word's score is within rounding
+    of the ground truth, and then by at most the number of such words."""
+    from oracle import c_oracle as CO
+    from oracle import vbq_oracle as o
+    g = golden("g10_analogy.npz")
+    emb, an = g["emb"], g["analogies"]
+    for e, want in ((emb, g["ranks"]), (g["quantized_7"].astype(np.float32), g["ranks_q7"])):
+        r64, near = o.prediction_ranks(e, an)
+        assert np.all(np.abs(r64 - want) <= near)
+        assert np.mean(r64 == want) > 0.95            # exact f64 breaks the f32 ties of integer-valued embeddings
+        rc = CO.analogy_ranks(e, an, threads=4)
+        assert np.all(np.abs(rc - want) <= near) and np.mean(rc == want) > 0.97
+    assert np.array_equal(o.quantize_coordinates(emb, 7), g["quantized_7"])
+    assert np.array_equal(o.quantize_coordinates(emb, 1023), g["quantized_1023"])
+    assert o.quantize_coordinates(emb, 7).dtype == np.float32

@@ -47,6 +47,9 @@ SIGNATURES = {
                                            C.c_void_p, C.c_void_p, C.c_void_p]),
     "vbq_nearest_code_f64": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p]),
+    "vbq_analogy_ranks_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int64]),
+    "vbq_analogy_ranks_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                        C.c_size_t, C.c_void_p]),
     "vbq_rans_encode_u16": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p]),
     "vbq_rans_decode_u16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p,

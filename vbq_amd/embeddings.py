@@ -5,6 +5,8 @@
     make_code_book(std, max_codepoint_length)    ipynb:383-390   (host: scipy ppf, as the notebook)
     compress_coordinates(means, stds, beta, ...) ipynb:429-443   (K1n)
     empirical_entropy(values)                    ipynb:452-455   (K2 histogram when indices are given)
+    prediction_ranks(emb, analogies_id)          ipynb:199-209   (fused f32 MFMA GEMM + count, vbq_ranks.hip)
+    test_beta / quantize_coordinates / test_quantization   ipynb:464-473, cells 36-37
 """
 from __future__ import annotations
 
@@ -91,12 +93,78 @@ def empirical_entropy(values) -> float:
     return entropy_from_counts(counts)
 
 
-def test_beta(means, stds, beta, codepoints, prediction_ranks=None):
-    """ipynb:464-473 (the notebook passes the (array, None) tuple on; the array is used here)."""
+def prediction_ranks(emb, analogies_id):
+    """ipynb cell 14 (ipynb:199-209).  `analogies_id` ([Q, 4] word ids) replaces the notebook's global.
+    emb: [V, K] array or device tensor.  Returns int64 ranks (NumPy in -> NumPy out)."""
+    import ctypes as C
+    from . import _lib
+    e = _dev(emb)
+    if e.dim() != 2:
+        raise ValueError("emb must be [V, K]")
+    an_np = analogies_id.cpu().numpy() if isinstance(analogies_id, torch.Tensor) else np.asarray(analogies_id)
+    if an_np.ndim != 2 or an_np.shape[1] != 4:
+        raise ValueError("analogies_id must be [Q, 4]")
+    V, K = e.shape
+    if an_np.size and (an_np.min() < 0 or an_np.max() >= V):
+        raise IndexError("analogy word id out of range")          # NumPy fancy indexing raises too
+    an = torch.from_numpy(np.ascontiguousarray(an_np, dtype=np.int32)).to(e.device)
+    Q = an.shape[0]
+    out = torch.empty(Q, dtype=torch.int64, device=e.device)
+    if Q == 0:
+        return out if isinstance(emb, torch.Tensor) else out.cpu().numpy()
+    h = _lib.lib()
+    nbytes = h.vbq_analogy_ranks_workspace_bytes(V, K, Q)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=e.device)
+    _lib.check(h.vbq_analogy_ranks_f32(ops._ptr(e), V, K, ops._ptr(an), Q, ops._ptr(out), ops._ptr(ws), C.c_size_t(nbytes),
+                                       ops._stream(e)), "vbq_analogy_ranks_f32")
+    return out if isinstance(emb, torch.Tensor) else out.cpu().numpy()
+
+
+def analogy_metrics(ranks):
+    """(mrr, acc, hits10) as computed in ipynb cells 30 and 37."""
+    r = ranks.cpu().numpy() if isinstance(ranks, torch.Tensor) else np.asarray(ranks)
+    return np.average(1 / (1 + r)), np.sum(r == 0) / len(r), np.sum(r < 10) / len(r)
+
+
+def quantize_coordinates(means, quantization_max):
+    """ipynb cell 36, the uniform-rounding baseline (torch on the device: two elementwise ops and a max)."""
+    m = _dev(means)
+    scale = (quantization_max + 0.5) / m.abs().max()
+    q = torch.round(torch.clamp(scale * m, -quantization_max, quantization_max))
+    return q if isinstance(means, torch.Tensor) else q.cpu().numpy()
+
+
+def test_quantization(means, quantization_max, analogies_id):
+    """ipynb cell 37: (mrr, acc, hits10, entropy, gzip, bz2, lzma bit lengths) of the rounding baseline.
+    The three general-purpose compressors run on the host, as in the notebook."""
+    import bz2
+    import gzip
+    import io
+    import lzma
+    quantized = np.asarray(quantize_coordinates(np.asarray(means), quantization_max))
+    mrr, acc, hits10 = analogy_metrics(prediction_ranks(quantized, analogies_id))
+    bits = empirical_entropy(quantized)
+    raw = bytes(quantized.astype(np.int8 if quantization_max <= 127 else np.int16).data)
+    buf = io.BytesIO()
+    with gzip.GzipFile(fileobj=buf, mode="wb", compresslevel=9) as f:
+        f.write(raw)
+    gz_bits = len(buf.getbuffer()) * 8
+    bz_bits = len(bz2.compress(raw, 9)) * 8
+    lz_bits = len(lzma.compress(raw, format=lzma.FORMAT_ALONE, preset=9)) * 8
+    return mrr, acc, hits10, bits, gz_bits, bz_bits, lz_bits
+
+
+def test_beta(means, stds, beta, codepoints, analogies_id=None):
+    """ipynb:464-473 (the notebook passes the (array, None) tuple on; the array is used here).  With
+    `analogies_id` returns (mrr, acc, hits10, bits) like the notebook; without it (compressed, bits).
+    Everything stays on the device: K1n -> K2 entropy -> fused rank GEMM."""
     idx, val = compress_coordinates_sweep(means, stds, [beta], codepoints)
     compressed = val[0]
     bits = entropy_from_indices(idx, N=int(np.log2(len(codepoints) + 1)) - 1)[0]
-    if prediction_ranks is None:
+    if analogies_id is None:
         return compressed, bits
-    ranks = np.asarray(prediction_ranks(compressed.cpu().numpy()))
-    return np.average(1 / (1 + ranks)), np.sum(ranks == 0) / len(ranks), np.sum(ranks < 10) / len(ranks), bits
+    if callable(analogies_id):                                       # a user-supplied prediction_ranks(emb)
+        ranks = np.asarray(analogies_id(compressed.cpu().numpy()))
+    else:
+        ranks = prediction_ranks(compressed.reshape(np.shape(means)), analogies_id)
+    return analogy_metrics(ranks) + (bits,)
