@@ -257,6 +257,26 @@ size_t vbq_analogy_ranks_workspace_bytes(int64_t V, int32_t K, int64_t Q);
 int vbq_analogy_ranks_f32(const float *d_emb, int64_t V, int32_t K, const int32_t *d_analogies, int64_t Q,
                           int64_t *d_out_ranks, void *d_workspace, size_t workspace_bytes, void *stream);
 
+/* ----------------------------------------------------------------------------------
+ * Image metrics (img-compression/img_comparison_metrics.py:6-220), batches
+ * [B][H][W][C], float64 arithmetic as in the reference.
+ *   vbq_image_sqerr_u8   per-image integer sum of (a - b)^2 (mse :6-16 = sum / n, psnr :19-33 from it)
+ *   vbq_u8_to_f64        widening copy (img.astype(float64), :122-123)
+ *   vbq_ssim_scale_f64   one scale of _SSIMForMultiScale (:84-157): 'valid' Gaussian window given as its
+ *                        separable factor d_window[size] (size <= 11), constants c1 = (k1 max_val)^2,
+ *                        c2 = (k2 max_val)^2; writes mean ssim and mean cs per image.  Direct sums where the
+ *                        reference uses fftconvolve: agreement to ~1e-10, not bit-exact.
+ *   vbq_downsample2_f64  scipy.ndimage.convolve(im, ones(1,2,2,1)/4, mode='reflect')[:, ::2, ::2, :] (:214-216)
+ * ---------------------------------------------------------------------------------- */
+int vbq_image_sqerr_u8(const uint8_t *d_img1, const uint8_t *d_img2, int64_t n_images, int64_t n_per_image,
+                       int64_t *d_out_sum, void *stream);
+int vbq_u8_to_f64(const uint8_t *d_in, int64_t n, double *d_out, void *stream);
+size_t vbq_ssim_scale_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t C, int32_t size);
+int vbq_ssim_scale_f64(const double *d_im1, const double *d_im2, int32_t B, int32_t H, int32_t W, int32_t C,
+                       const double *d_window, int32_t size, double c1, double c2, double *d_out_ssim,
+                       double *d_out_cs, void *d_workspace, size_t workspace_bytes, void *stream);
+int vbq_downsample2_f64(const double *d_in, int32_t B, int32_t H, int32_t W, int32_t C, double *d_out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -637,3 +637,70 @@ def quantize_coordinates(means, quantization_max):
     """ipynb cell 36: uniform rounding baseline."""
     scale = (quantization_max + 0.5) / np.abs(means).max()
     return np.round(np.clip(scale * means, -quantization_max, quantization_max))
+
+
+# ---------------------------------------------------------------------------------------------
+# f4: image metrics (img-compression/img_comparison_metrics.py), NumPy restatement with DIRECT sums
+# (the reference's fftconvolve is not bit-reproducible; agreement ~1e-10).
+# ---------------------------------------------------------------------------------------------
+def image_mse(img1, img2):
+    """img_comparison_metrics.py:6-16."""
+    a, b = np.asarray(img1, np.float64), np.asarray(img2, np.float64)
+    return np.mean(np.square(a - b), axis=(1, 2, 3))
+
+
+def image_psnr(img1, img2, max_val=255):
+    """img_comparison_metrics.py:19-33."""
+    return 20 * np.log10(max_val) - 10 * np.log10(image_mse(img1, img2))
+
+
+def _gauss_window_1d(size, sigma):
+    radius = size // 2
+    x = np.arange(size, dtype=np.float64) - radius + (0.5 if size % 2 == 0 else 0.0)
+    e = np.exp(-(x ** 2) / (2.0 * sigma ** 2))
+    return e / e.sum()
+
+
+def _valid_filter(x, w):
+    """Separable 'valid' correlation of [B, H, W, C] with the symmetric window w along H and W."""
+    n = len(w)
+    t = sum(w[k] * x[:, :, k:x.shape[2] - n + 1 + k, :] for k in range(n))
+    return sum(w[k] * t[:, k:t.shape[1] - n + 1 + k, :, :] for k in range(n))
+
+
+def ssim_scale(im1, im2, max_val=255, filter_size=11, filter_sigma=1.5, k1=0.01, k2=0.03):
+    """img_comparison_metrics.py:84-157."""
+    _, H, W, _ = im1.shape
+    size = min(filter_size, H, W)
+    w = _gauss_window_1d(size, size * filter_sigma / filter_size)
+    mu1, mu2 = _valid_filter(im1, w), _valid_filter(im2, w)
+    s11 = _valid_filter(im1 * im1, w) - mu1 * mu1
+    s22 = _valid_filter(im2 * im2, w) - mu2 * mu2
+    s12 = _valid_filter(im1 * im2, w) - mu1 * mu2
+    c1, c2 = (k1 * max_val) ** 2, (k2 * max_val) ** 2
+    v1, v2 = 2.0 * s12 + c2, s11 + s22 + c2
+    ssim = np.mean(((2.0 * mu1 * mu2 + c1) * v1) / ((mu1 * mu1 + mu2 * mu2 + c1) * v2), axis=(1, 2, 3))
+    return ssim, np.mean(v1 / v2, axis=(1, 2, 3))
+
+
+def downsample2(im):
+    """scipy.ndimage.convolve(im, ones((1,2,2,1))/4, mode='reflect')[:, ::2, ::2, :] (:214-216):
+    mean of the 2x2 block starting at (2y, 2x), indices clamped at the far edge."""
+    _, H, W, _ = im.shape
+    y0, x0 = np.arange(0, H, 2), np.arange(0, W, 2)
+    y1, x1 = np.minimum(y0 + 1, H - 1), np.minimum(x0 + 1, W - 1)
+    return 0.25 * ((im[:, y0][:, :, x0] + im[:, y0][:, :, x1]) + (im[:, y1][:, :, x0] + im[:, y1][:, :, x1]))
+
+
+def ms_ssim(img1, img2, max_val=255, weights=(0.0448, 0.2856, 0.3001, 0.2363, 0.1333)):
+    """img_comparison_metrics.py:160-220."""
+    w = np.array(weights)
+    im1, im2 = np.asarray(img1, np.float64), np.asarray(img2, np.float64)
+    mssim, mcs = [], []
+    for _ in range(w.size):
+        s, c = ssim_scale(im1, im2, max_val=max_val)
+        mssim.append(s)
+        mcs.append(c)
+        im1, im2 = downsample2(im1), downsample2(im2)
+    mcs, mssim = np.array(mcs), np.array(mssim)
+    return np.prod(mcs[:-1] ** w[:-1, None], axis=0) * (mssim[-1] ** w[-1])

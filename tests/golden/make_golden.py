@@ -249,6 +249,28 @@ def g10():
          ranks_q7=ranks_q7.astype(np.int64), **{f"quantized_{k}": v.astype(np.int16) for k, v in qz.items()})      # integer-valued f32, stored as int16
 
 
+# ---------------------------------------------------------------- G11 (image metrics)
+def g11():
+    """img_comparison_metrics.mse / psnr / ms_ssim (NumPy + SciPy only: imported as is) on seeded uint8 batches:
+    smooth images plus noise of increasing strength, three shapes incl. one smaller than the 11-tap window."""
+    sys.path.insert(0, os.path.join(REF, "img-compression"))
+    import img_comparison_metrics as M
+    rng = np.random.default_rng(111)
+    out = {}
+    for name, (B, H, W, Cc) in {"a": (3, 72, 104, 3), "b": (2, 96, 80, 1), "c": (2, 40, 24, 2)}.items():
+        yy, xx = np.mgrid[0:H, 0:W]
+        base = 128 + 90 * np.sin(yy[None, :, :, None] / 7.0 + np.arange(B)[:, None, None, None]) * np.cos(
+            xx[None, :, :, None] / 5.0 + np.arange(Cc)[None, None, None, :])
+        x = np.clip(base + rng.normal(0, 6, (B, H, W, Cc)), 0, 255).astype(np.uint8)
+        y = np.clip(x.astype(np.float64) + rng.normal(0, 1, (B, H, W, Cc)) * (3 + 9 * np.arange(B))[:, None, None, None], 0,
+                    255).astype(np.uint8)
+        out[f"{name}_x"], out[f"{name}_y"] = x, y
+        out[f"{name}_mse"] = M.mse(x, y)
+        out[f"{name}_psnr"] = M.psnr(x, y, max_val=255)
+        out[f"{name}_msssim"] = M.ms_ssim(x, y, max_val=255)
+    save("g11_image_metrics.npz", **out)
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "reference tree not found; this script only runs in the build container"
     g1_g2_g3()
@@ -257,3 +279,4 @@ if __name__ == "__main__":
     g7()
     g9()
     g10()
+    g11()

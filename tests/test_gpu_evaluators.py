@@ -72,3 +72,90 @@ def test_full_size_properties_and_test_beta():
     cp, _ = E.make_code_book(E.empirical_std(emb[:2000]))
     out = E.test_beta(emb[:2000], stds, 1.0, cp, analogies_id=an[:200] % 2000)
     assert len(out) == 4 and out[3] > 0
+
+
+def test_image_metrics_golden(golden):
+    """mse / psnr bit-exact, ms_ssim to 1e-9 against the reference module's outputs (g11) and the oracle."""
+    _need_gpu()
+    from oracle import vbq_oracle as o
+    from vbq_amd import metrics as M
+    g = golden("g11_image_metrics.npz")
+    for k in "abc":
+        x, y = g[f"{k}_x"], g[f"{k}_y"]
+        assert np.array_equal(M.mse(x, y), g[f"{k}_mse"])
+        assert np.array_equal(M.psnr(x, y, max_val=255), g[f"{k}_psnr"])
+        got = M.ms_ssim(x, y, max_val=255)
+        np.testing.assert_allclose(got, g[f"{k}_msssim"], rtol=1e-9, atol=0)
+        np.testing.assert_allclose(got, o.ms_ssim(x, y), rtol=1e-12, atol=0)
+    assert np.array_equal(M.ms_ssim(g["a_x"], g["a_x"]), np.ones(3))            # identical images
+    with pytest.raises(RuntimeError):
+        M.mse(g["a_x"], g["b_x"])
+    with pytest.raises(RuntimeError):
+        M.ms_ssim(g["a_x"][0], g["a_x"][0])
+
+
+def test_image_metrics_kodak_size():
+    """One Kodak-sized image against 8 reconstructions (the M axis of utils.evaluate_compression_quantizer):
+    scales and the 2x2 decimation against the oracle at full size, monotone in the noise level."""
+    _need_gpu()
+    from oracle import vbq_oracle as o
+    from vbq_amd import metrics as M
+    rng = np.random.default_rng(3)
+    H, W = 512, 768
+    yy, xx = np.mgrid[0:H, 0:W]
+    x = np.clip(128 + 80 * np.sin(yy / 17.0)[..., None] * np.cos(xx / 11.0)[..., None] + rng.normal(0, 10, (H, W, 3)), 0, 255)
+    x = x.astype(np.uint8)
+    xs = np.repeat(x[None], 8, axis=0)
+    ys = np.clip(xs + rng.normal(0, 1, xs.shape) * (1 + 4 * np.arange(8))[:, None, None, None], 0, 255).astype(np.uint8)
+    got = M.ms_ssim(xs, ys)
+    assert np.all(np.diff(got) < 0) and got[0] > 0.99
+    np.testing.assert_allclose(got[[0, 7]], o.ms_ssim(xs[[0, 7]], ys[[0, 7]]), rtol=1e-12)
+    assert np.array_equal(M.mse(xs, ys), o.image_mse(xs, ys))
+    assert np.allclose(M.convert_to_db(got), -10 * np.log10(1 - got))
+
+
+def test_evaluate_compression_quantizer(tmp_path):
+    """utils.evaluate_compression_quantizer end to end on two PNG files with a stand-in VAE: result keys, shapes,
+    bit accounting equal to the compress() dict, metrics equal to the oracle on the same reconstructions."""
+    _need_gpu()
+    from PIL import Image
+    from oracle import vbq_oracle as o
+    from vbq_amd import ChannelwisePriorCDFQuantizer, priors, utils
+    rng = np.random.default_rng(8)
+    C, H, W = 4, 48, 64
+
+    class VAE:
+        def encode(self, X):
+            r = np.random.default_rng(int(X.sum() * 1000) % 2 ** 31)
+            return (r.normal(0, 1, (1, H // 4, W // 4, C)).astype(np.float32),
+                    r.normal(-4, 0.5, (1, H // 4, W // 4, C)).astype(np.float32))
+
+        def decode(self, Z):
+            Z = np.asarray(Z)
+            up = np.repeat(np.repeat(Z[..., :3], 4, axis=1), 4, axis=2)
+            return 0.5 + 0.2 * up
+
+    files = []
+    for i in range(2):
+        arr = rng.integers(0, 256, (H, W, 3)).astype(np.uint8)
+        p = tmp_path / f"img{i}.png"
+        Image.fromarray(arr).save(p)
+        files.append(str(p))
+    q = ChannelwisePriorCDFQuantizer(C, 10)
+    q.build_code_points(priors.FactoredGaussianPrior(np.zeros(C), np.ones(C)))
+    lambs = [0.01, 1.0, 30.0]
+    vae = VAE()
+    q.build_entropy_models(np.asarray(Image.open(files[0]).convert("RGB"))[None] / 255., vae, lambs, add_n_smoothing=1)
+    res = utils.evaluate_compression_quantizer(q, vae, files, lambs, return_reconstructions=True)
+    for key in ("B", "BPP", "BPPCL", "BPL", "MSE (RGB)", "PSNR (Luma)", "MS-SSIM (Chroma)", "MS-SSIM (RGB) (dB)"):
+        assert res[key].shape == (2, 3), key
+    assert len(res["reconstructions"]) == 2 and res["reconstructions"][0].shape == (3, H, W, 3)
+    assert np.all(np.diff(res["B"], axis=1) <= 0)                       # rate falls as lambda grows
+    x = np.asarray(Image.open(files[1]).convert("RGB"))
+    xs = np.repeat(x[None], 3, axis=0)
+    assert np.array_equal(res["MSE (RGB)"][1], o.image_mse(xs, res["reconstructions"][1]))
+    np.testing.assert_allclose(res["MS-SSIM (RGB)"][1], o.ms_ssim(xs, res["reconstructions"][1]), rtol=1e-12)
+    out = q.compress(x[None] / 255., vae, lambs)
+    assert res["B"][1, 0] == np.sum(out["num_bits"][lambs[0]])
+    with pytest.raises(Exception):
+        utils.evaluate_compression_quantizer(q, vae, files, lambs, use_tf=True)

@@ -221,3 +221,15 @@ def test_g10_prediction_ranks(golden):
     assert np.array_equal(o.quantize_coordinates(emb, 7), g["quantized_7"])
     assert np.array_equal(o.quantize_coordinates(emb, 1023), g["quantized_1023"])
     assert o.quantize_coordinates(emb, 7).dtype == np.float32
+
+
+def test_g11_image_metrics(golden):
+    """f4: direct-sum restatement of mse / psnr / ms_ssim vs the reference module (fftconvolve): mse and psnr
+    bit-exact (integer-valued sums), ms_ssim to 1e-9 relative."""
+    from oracle import vbq_oracle as o
+    g = golden("g11_image_metrics.npz")
+    for k in "abc":
+        x, y = g[f"{k}_x"], g[f"{k}_y"]
+        assert np.array_equal(o.image_mse(x, y), g[f"{k}_mse"])
+        assert np.array_equal(o.image_psnr(x, y), g[f"{k}_psnr"])
+        np.testing.assert_allclose(o.ms_ssim(x, y), g[f"{k}_msssim"], rtol=1e-9, atol=0)

@@ -94,3 +94,68 @@ def quantize_indep_dims(z, code_points, code_lengths, fun, lamb, backend=np, mod
     K = len(z)
     Zd, Bd = batch_quantize_indep_dims((1, K), code_points, code_lengths, fun, [lamb], return_np=True, mode=mode)
     return Zd[lamb][0], Bd[lamb][0]
+
+
+def convert_to_db(d):
+    """utils.py:497-499 (BMSHJ ICLR 2018, p. 8)."""
+    return -10 * np.log10(1 - d)
+
+
+def evaluate_compression_quantizer(quantizer, vae, test_img_files, settings, model_input_float_type="float32",
+                                   return_reconstructions=False, use_tf=False):
+    """utils.py:502-634: compress every image with `quantizer.compress(X, vae, settings, clip=True)` and report bits
+    and image quality per (image, setting).  Same result dict (keys 'B', 'BPP', 'BPPCL', 'BPL', '<metric> (<mode>)'
+    for MSE / PSNR / MS-SSIM x RGB / Luma / Chroma, 'MS-SSIM (<mode>) (dB)', 'reconstructions').  Image I/O and
+    colour conversion stay with PIL on the host, as in the reference; the metrics of all M reconstructions of an
+    image are evaluated in one batch on the GPU (vbq_amd.metrics).  `use_tf=True` (TensorFlow's ssim ops) is not
+    available."""
+    from PIL import Image
+
+    from . import metrics as img_comparison_metrics
+    if use_tf:
+        raise VBQError("use_tf=True needs TensorFlow's image ops; this build evaluates mse / psnr / ms_ssim natively")
+    N, M = len(test_img_files), len(settings)
+    results = {"reconstructions": []}
+    for key in ("B", "BPP", "BPPCL", "BPL"):
+        results[key] = np.empty([N, M])
+    modes = ("RGB", "Luma", "Chroma")
+    results.update({"%s (%s)" % (metric, mode): np.empty([N, M]) for mode in modes for metric in ("MSE", "PSNR", "MS-SSIM")})
+    for n, f in enumerate(test_img_files):
+        orig = Image.open(f)
+        img = orig.convert("RGB")
+        num_pixels = orig.size[0] * orig.size[1]
+        x = np.asarray(img)
+        X = (x / 255.)[None, ...].astype(model_input_float_type)
+        tmp = quantizer.compress(X, vae, settings, clip=True)
+        img_hats, x_hats = [], []
+        for m, lamb in enumerate(settings):
+            num_bits = np.asarray(tmp["num_bits"][lamb])[0]
+            nbits = np.sum(num_bits)
+            results["B"][n, m] = nbits
+            results["BPP"][n, m] = nbits / num_pixels
+            results["BPL"][n, m] = nbits / num_bits.size
+            num_bits_cl = tmp.get("num_bits_cl", tmp["num_bits"])
+            results["BPPCL"][n, m] = np.sum(np.asarray(num_bits_cl[lamb])[0]) / num_pixels
+            X_hat = np.asarray(tmp["X_hat"][lamb])[0]
+            x_hat = np.clip(np.round(X_hat * 255), 0, 255).astype(np.uint8)
+            img_hats.append(Image.fromarray(x_hat))
+            x_hats.append(x_hat)
+        x_yc = np.asarray(img.convert("YCbCr"))
+        x_hats = np.asarray(x_hats)
+        x_hats_yc = np.array([np.asarray(h.convert("YCbCr")) for h in img_hats])
+        if return_reconstructions:
+            results["reconstructions"].append(x_hats)
+        for mode in modes:
+            if mode == "RGB":
+                x_comp, x_hats_comp = x, x_hats
+            elif mode == "Luma":
+                x_comp, x_hats_comp = x_yc[..., 0:1], x_hats_yc[..., 0:1]
+            else:
+                x_comp, x_hats_comp = x_yc[..., 1:], x_hats_yc[..., 1:]
+            xs_comp = np.repeat(np.ascontiguousarray(x_comp)[None, ...], repeats=M, axis=0)
+            x_hats_comp = np.ascontiguousarray(x_hats_comp)
+            results["MSE (%s)" % mode][n] = img_comparison_metrics.mse(xs_comp, x_hats_comp)
+            results["PSNR (%s)" % mode][n] = img_comparison_metrics.psnr(xs_comp, x_hats_comp, max_val=255)
+            results["MS-SSIM (%s)" % mode][n] = img_comparison_metrics.ms_ssim(xs_comp, x_hats_comp, max_val=255)
+    results.update({"%s (dB)" % k: convert_to_db(v) for k, v in results.items() if "MS-SSIM" in k})
+    return results
