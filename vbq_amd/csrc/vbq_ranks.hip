@@ -25,30 +25,63 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));      // native vector (
 
 constexpr int kBM = 128;          // questions per workgroup tile
 constexpr int kBN = 128;          // words per workgroup tile
-constexpr int kBK = 32;           // k per LDS stage (2 stages x 2 operands x 16 KB = 64 KB of LDS, 2 workgroups per CU)
+#ifndef VBQ_RANK_BK
+#define VBQ_RANK_BK 32
+#endif
+#ifndef VBQ_RANK_WGS
+#define VBQ_RANK_WGS 2
+#endif
+constexpr int kBK = VBQ_RANK_BK;  // k per LDS stage (32: 2 stages x 2 operands x 16 KB = 64 KB of LDS, 2 workgroups per CU)
 constexpr int kRankThreads = 256; // 4 waves, each a 64 x 64 quadrant = 2 x 2 MFMA tiles
 
-// normed^T [Kp][Vp]: row norms in f32 with a sequential sum (NumPy's pairwise sum differs in the last
-// bits; the test tolerance covers it), zero padding for k >= K and v >= V.
+// normed^T [Kp][Vp] and the denominators 1e-8 + |emb_v| [Vp].  Row norms are f32 sums in index order
+// (NumPy's pairwise sum differs in the last bits; the test tolerance covers it).  A workgroup owns 64 words:
+// the embedding is read in coalesced 64 x 64 slabs through LDS, thread r < 64 adds up row r in k order,
+// and the normalised slab leaves transposed, again coalesced.  Zero padding for k >= K and v >= V.
 __global__ void __launch_bounds__(256)
-k_normalize_t(const float *__restrict__ emb, long V, int K, int Kp, long Vp, float *__restrict__ nT) {
-    const long v = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= Vp) return;
-    if (v >= V) {
-        for (int k = 0; k < Kp; ++k) nT[(long)k * Vp + v] = 0.0f;
-        return;
-    }
-    const float *row = emb + v * K;
+k_normalize_t(const float *__restrict__ emb, long V, int K, int Kp, long Vp, float *__restrict__ nT, float *__restrict__ den) {
+    __shared__ float tile[64][65];
+    __shared__ float dn[64];
+    const long v0 = (long)blockIdx.x * 64;
+    const int tid = threadIdx.x;
     float s = 0.0f;
-    for (int k = 0; k < K; ++k) s = __fadd_rn(s, __fmul_rn(row[k], row[k]));
-    const float den = __fadd_rn(1e-8f, __fsqrt_rn(s));
-    for (int k = 0; k < Kp; ++k) nT[(long)k * Vp + v] = k < K ? __fdiv_rn(row[k], den) : 0.0f;
+    for (int k0 = 0; k0 < K; k0 += 64) {
+        for (int i = tid; i < 64 * 64; i += 256) {
+            const int r = i >> 6, j = i & 63;
+            tile[r][j] = (v0 + r < V && k0 + j < K) ? emb[(v0 + r) * K + k0 + j] : 0.0f;
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const int kn = K - k0 < 64 ? K - k0 : 64;
+            for (int j = 0; j < kn; ++j) s = __fadd_rn(s, __fmul_rn(tile[tid][j], tile[tid][j]));
+        }
+        __syncthreads();
+    }
+    if (tid < 64) {
+        dn[tid] = __fadd_rn(1e-8f, __fsqrt_rn(s));
+        if (v0 + tid < Vp) den[v0 + tid] = dn[tid];
+    }
+    __syncthreads();
+    for (int k0 = 0; k0 < Kp; k0 += 64) {
+        for (int i = tid; i < 64 * 64; i += 256) {
+            const int r = i >> 6, j = i & 63;
+            tile[r][j] = (v0 + r < V && k0 + j < K) ? __fdiv_rn(emb[(v0 + r) * K + k0 + j], dn[r]) : 0.0f;
+        }
+        __syncthreads();
+        for (int i = tid; i < 64 * 64; i += 256) {
+            const int j = i >> 6, r = i & 63;
+            if (k0 + j < Kp && v0 + r < Vp) nT[(long)(k0 + j) * Vp + v0 + r] = tile[r][j];
+        }
+        __syncthreads();
+    }
 }
 
-// pred^T [Kp][Qp] and the ground-truth score of every question (same fma chain as the MFMA).
+// pred^T [Kp][Qp] and the ground-truth score of every question (same fma chain as the MFMA).  The four
+// words of a question are re-normalised from their embedding rows (contiguous) with the stored denominators:
+// the same IEEE division as in k_normalize_t, hence the same numbers as in normed^T.
 __global__ void __launch_bounds__(256)
-k_pred_gt(const float *__restrict__ nT, long Vp, int Kp, const int32_t *__restrict__ an, long Q, long Qp,
-          float *__restrict__ pT, float *__restrict__ gt) {
+k_pred_gt(const float *__restrict__ emb, const float *__restrict__ den, int K, int Kp, const int32_t *__restrict__ an, long Q,
+          long Qp, float *__restrict__ pT, float *__restrict__ gt) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= Qp) return;
     if (i >= Q) {
@@ -57,19 +90,24 @@ k_pred_gt(const float *__restrict__ nT, long Vp, int Kp, const int32_t *__restri
         return;
     }
     const long a = an[4 * i], b = an[4 * i + 1], c = an[4 * i + 2], d = an[4 * i + 3];
+    const float *ea = emb + a * K, *eb = emb + b * K, *ec = emb + c * K, *ed = emb + d * K;
+    const float da = den[a], db = den[b], dc = den[c], dd = den[d];
     float acc = 0.0f;
     for (int k = 0; k < Kp; ++k) {
-        const float *r = nT + (long)k * Vp;
-        const float p = __fadd_rn(__fsub_rn(r[b], r[a]), r[c]);       // (normed[b] - normed[a]) + normed[c]
+        float p = 0.0f, t = 0.0f;
+        if (k < K) {
+            p = __fadd_rn(__fsub_rn(__fdiv_rn(eb[k], db), __fdiv_rn(ea[k], da)), __fdiv_rn(ec[k], dc));   // (nb - na) + nc
+            t = __fdiv_rn(ed[k], dd);
+        }
         pT[(long)k * Qp + i] = p;
-        acc = __fmaf_rn(p, r[d], acc);
+        acc = __fmaf_rn(p, t, acc);
     }
     gt[i] = acc;
 }
 
 // One workgroup: 128 questions x a range of 128-word tiles.  LDS holds [k][m] slabs so that a
 // wave's operand fetch (lane l: row l & 31, k = l >> 5) is one conflict-free ds_read_b32.
-__global__ void __launch_bounds__(kRankThreads, 2)
+__global__ void __launch_bounds__(kRankThreads, VBQ_RANK_WGS)
 k_rank_gemm(const float *__restrict__ pT, const float *__restrict__ nT, const float *__restrict__ gt, long Qp, long Vp,
             long V, int Kp, int K2, int tiles_per_wg, int *__restrict__ below) {
     __shared__ __align__(16) float As[2][kBK][kBM];
@@ -199,7 +237,7 @@ __global__ void k_rank_finish(const int *__restrict__ below, long Q, long V, int
 struct RankLayout {
     long Vp, Qp;
     int Kp;
-    size_t off_nT, off_pT, off_gt, off_below, total;
+    size_t off_nT, off_pT, off_gt, off_below, off_den, total;
 };
 
 RankLayout rank_layout(int64_t V, int32_t K, int64_t Q) {
@@ -212,7 +250,8 @@ RankLayout rank_layout(int64_t V, int32_t K, int64_t Q) {
     r.off_pT = al(r.off_nT + sizeof(float) * (size_t)r.Kp * r.Vp);
     r.off_gt = al(r.off_pT + sizeof(float) * (size_t)r.Kp * r.Qp);
     r.off_below = al(r.off_gt + sizeof(float) * (size_t)r.Qp);
-    r.total = al(r.off_below + sizeof(int) * (size_t)r.Qp);
+    r.off_den = al(r.off_below + sizeof(int) * (size_t)r.Qp);
+    r.total = al(r.off_den + sizeof(float) * (size_t)r.Vp);
     return r;
 }
 
@@ -240,21 +279,21 @@ extern "C" int vbq_analogy_ranks_f32(const float *d_emb, int64_t V, int32_t K, c
     float *nT = reinterpret_cast<float *>(ws + r.off_nT), *pT = reinterpret_cast<float *>(ws + r.off_pT);
     float *gt = reinterpret_cast<float *>(ws + r.off_gt);
     int *below = reinterpret_cast<int *>(ws + r.off_below);
+    float *den = reinterpret_cast<float *>(ws + r.off_den);
     if (hipMemsetAsync(below, 0, sizeof(int) * (size_t)r.Qp, st) != hipSuccess) {
         set_error("vbq_analogy_ranks_f32: hipMemsetAsync failed");
         return VBQ_ERR_LAUNCH;
     }
-    hipLaunchKernelGGL(k_normalize_t, dim3((unsigned)((r.Vp + 255) / 256)), dim3(256), 0, st, d_emb, (long)V, (int)K, r.Kp,
-                       r.Vp, nT);
-    hipLaunchKernelGGL(k_pred_gt, dim3((unsigned)((r.Qp + 255) / 256)), dim3(256), 0, st, nT, r.Vp, r.Kp, d_analogies, (long)Q,
-                       r.Qp, pT, gt);
+    hipLaunchKernelGGL(k_normalize_t, dim3((unsigned)(r.Vp / 64)), dim3(256), 0, st, d_emb, (long)V, (int)K, r.Kp, r.Vp, nT, den);
+    hipLaunchKernelGGL(k_pred_gt, dim3((unsigned)((r.Qp + 255) / 256)), dim3(256), 0, st, d_emb, den, (int)K, r.Kp, d_analogies,
+                       (long)Q, r.Qp, pT, gt);
     // question blocks x word-tile ranges.  2 workgroups fit a CU; pick the split whose last wave of
     // workgroups wastes the least: time ~ ceil(qb * splits / 512) * tiles_per_wg
     const long qb = r.Qp / kBM, nt = r.Vp / kBN;
     long best_s = 1, best_cost = -1;
     for (long s = 1; s <= nt && s <= 256; ++s) {
         const long tpw = (nt + s - 1) / s;
-        const long cost = ((qb * s + 511) / 512) * tpw;
+        const long cost = ((qb * s + 256 * VBQ_RANK_WGS - 1) / (256 * VBQ_RANK_WGS)) * tpw;
         if (best_cost < 0 || cost < best_cost || (cost == best_cost && tpw >= 8 && s > best_s)) { best_cost = cost; best_s = s; }
     }
     const int tiles_per_wg = (int)((nt + best_s - 1) / best_s);
