@@ -298,3 +298,13 @@ def test_quantizer_with_repeated_code_points():
         for l in lambs:
             assert np.array_equal(out["Z_hat"][l][0], ref["Z_hat"][np.float32(l)])
             assert np.array_equal(out["num_bits"][l][0], ref["num_bits"][np.float32(l)])
+
+
+@pytest.mark.parametrize("rows,cols", [(1, 1), (3, 5), (64, 64), (100, 36), (260, 132), (36864 // 8, 256), (67, 128), (128, 67)])
+def test_transpose_scalar_and_vector_paths(rows, cols):
+    """vbq_transpose_f32: the 16-byte path (rows, cols multiples of 4) and the scalar path, ragged tiles included."""
+    from vbq_amd import ops
+    rng = np.random.default_rng(rows * 1000 + cols)
+    x = rng.normal(size=(rows, cols)).astype(np.float32)
+    got = ops.transpose(torch.from_numpy(x).cuda()).cpu().numpy()
+    assert got.shape == (cols, rows) and np.array_equal(got, x.T)

@@ -305,6 +305,30 @@ k_transpose(const float *__restrict__ in, long rows, long cols, float *__restric
     }
 }
 
+// Same tiles with 16-byte global accesses (rows and cols multiples of 4, 16-byte aligned pointers).
+__global__ void __launch_bounds__(256)
+k_transpose_v4(const float *__restrict__ in, long rows, long cols, float *__restrict__ out) {
+    __shared__ float tile[64][65];
+    const long r0 = (long)blockIdx.y * 64, c0 = (long)blockIdx.x * 64;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = threadIdx.x + 256 * k, lr = i >> 4, lc = (i & 15) * 4;
+        const long r = r0 + lr, c = c0 + lc;
+        if (r < rows && c < cols) {
+            const float4 v = *reinterpret_cast<const float4 *>(in + r * cols + c);
+            tile[lr][lc] = v.x; tile[lr][lc + 1] = v.y; tile[lr][lc + 2] = v.z; tile[lr][lc + 3] = v.w;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = threadIdx.x + 256 * k, lc = i >> 4, lr = (i & 15) * 4;
+        const long c = c0 + lc, r = r0 + lr;
+        if (r < rows && c < cols)
+            *reinterpret_cast<float4 *>(out + c * rows + r) = make_float4(tile[lr][lc], tile[lr + 1][lc], tile[lr + 2][lc], tile[lr + 3][lc]);
+    }
+}
+
 }  // namespace
 }  // namespace vbq
 
@@ -419,8 +443,14 @@ extern "C" int vbq_transpose_f32(const float *d_in, int64_t n_rows, int64_t n_co
     if (n_rows == 0 || n_cols == 0) return VBQ_OK;
     VBQ_REQUIRE(d_in && d_out && d_in != d_out, VBQ_ERR_INVALID_ARGUMENT, "vbq_transpose_f32: null or aliased pointers");
     VBQ_REQUIRE((n_rows + 63) / 64 <= 65535, VBQ_ERR_UNSUPPORTED, "vbq_transpose_f32: more than 4.19e6 rows");
-    hipLaunchKernelGGL(k_transpose, dim3((unsigned)((n_cols + 63) / 64), (unsigned)((n_rows + 63) / 64)), dim3(256), 0,
-                       reinterpret_cast<hipStream_t>(stream), d_in, (long)n_rows, (long)n_cols, d_out);
+    const bool v4 = n_rows % 4 == 0 && n_cols % 4 == 0 && ((reinterpret_cast<uintptr_t>(d_in) | reinterpret_cast<uintptr_t>(d_out)) & 15) == 0;
+    const dim3 grid((unsigned)((n_cols + 63) / 64), (unsigned)((n_rows + 63) / 64));
+    if (v4)
+        hipLaunchKernelGGL(k_transpose_v4, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), d_in, (long)n_rows,
+                           (long)n_cols, d_out);
+    else
+        hipLaunchKernelGGL(k_transpose, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), d_in, (long)n_rows,
+                           (long)n_cols, d_out);
     VBQ_CHECK_LAUNCH("transpose");
     return VBQ_OK;
 }
