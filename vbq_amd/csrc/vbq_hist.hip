@@ -13,6 +13,9 @@ namespace vbq {
 namespace {
 
 constexpr int kHistThreads = 256;
+#ifndef VBQ_HIST_U
+#define VBQ_HIST_U 2
+#endif
 
 // LDS slot of rank index q.  In rank order every code point of bit levels 0..5 sits at
 // q = 31 (mod 32) -- one LDS bank -- and those are exactly the bins that fill up at large
@@ -28,7 +31,8 @@ __device__ __forceinline__ unsigned int bin_slot(unsigned int q) { return q ^ (q
 // lanes); (2) the lanes whose first index equals the wave leader's are summed with four
 // ballots and added by one lane.  Spread-out distributions pay ~10 extra VALU ops per index.
 constexpr int kHistCopies = 4;            // private copies of the bins per workgroup (lane & 3 picks one); 8 copies measured slower
-constexpr int kHistCopyStride = 2048 + 8; // words; +8 rotates each copy by 8 banks
+// The copies of a bin are adjacent words (word = 4 * slot + copy): lanes of different copies never meet on a
+// bank, and zeroing / flushing the 32 KB moves 16 bytes per LDS instruction.
 
 __device__ __forceinline__ void hist_add8(unsigned int *h, const uint4 v) {
     unsigned int s[8];
@@ -56,12 +60,12 @@ __device__ __forceinline__ void hist_add8(unsigned int *h, const uint4 v) {
     const unsigned long long same_mask = __ballot(same);
     const int first = __ffsll((long long)same_mask) - 1;
     const int lane = threadIdx.x & 63;
-    unsigned int *hc = h + (lane & (kHistCopies - 1)) * kHistCopyStride;   // this lane's copy of the bins
-    if (lane == first) atomicAdd(&hc[lead], tot);
-    if (!same) atomicAdd(&hc[s[0]], cnt);
+    unsigned int *hc = h + (lane & (kHistCopies - 1));                      // this lane's copy of the bins
+    if (lane == first) atomicAdd(&hc[kHistCopies * lead], tot);
+    if (!same) atomicAdd(&hc[kHistCopies * s[0]], cnt);
 #pragma unroll
     for (int k = 1; k < 8; ++k)
-        if (!eq[k]) atomicAdd(&hc[s[k]], 1u);
+        if (!eq[k]) atomicAdd(&hc[kHistCopies * s[k]], 1u);
 }
 
 // All indices of the workgroup belong to one channel: [l][c][n_per_ch] contiguous.
@@ -71,40 +75,64 @@ k_hist_flat(const uint16_t *__restrict__ idx, long n_per_ch, int C, long E,
             CountT *__restrict__ counts, int vec_ok) {
     constexpr int T = table_size(N);
     static_assert(T + 1 <= 2048, "bin copies are laid out for at most 2048 bins");
-    __shared__ unsigned int h[kHistCopies * kHistCopyStride];
+    __shared__ __align__(16) unsigned int h[kHistCopies * 2048];
     const int c = blockIdx.y, l = blockIdx.z;
-    for (int i = threadIdx.x; i < kHistCopies * kHistCopyStride; i += blockDim.x) h[i] = 0;
-    __syncthreads();
     const uint16_t *src = idx + (long)l * E + (long)c * n_per_ch;
     const long noct = vec_ok ? (n_per_ch >> 3) : 0;
     const long stride = (long)gridDim.x * blockDim.x;
     long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
     // iterations in which every lane of the wave has two full loads take the aggregated path
     const int lane = threadIdx.x & 63;
-    for (; (q - lane) + 63 + stride < noct; q += 2 * stride) {
-        const uint4 v0 = *reinterpret_cast<const uint4 *>(src + q * 8);
-        const uint4 v1 = *reinterpret_cast<const uint4 *>(src + (q + stride) * 8);
-        hist_add8(h, v0);
-        hist_add8(h, v1);
+    // Software-pipelined in two register stages of U 16-byte loads per lane: one stage is in flight while the
+    // other is counted (Little's law: 20 waves per CU x 64 lanes x U x 16 B must cover the HBM latency); the
+    // first stage is issued before the bins are cleared.  "full": every lane of the wave has all U loads.
+    constexpr int U = VBQ_HIST_U;
+    auto full = [&](long qq, int n) { return (qq - lane) + 63 + (long)(n - 1) * stride < noct; };
+    uint4 A[U], B[U];
+    bool haveA = full(q, U);
+    if (haveA) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) A[u] = *reinterpret_cast<const uint4 *>(src + (q + u * stride) * 8);
+        q += U * stride;
     }
+    for (int i = threadIdx.x; i < 2048; i += blockDim.x) reinterpret_cast<uint4 *>(h)[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    while (haveA) {
+        const bool haveB = full(q, U);
+        if (haveB) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) B[u] = *reinterpret_cast<const uint4 *>(src + (q + u * stride) * 8);
+            q += U * stride;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) hist_add8(h, A[u]);
+        if (!haveB) break;
+        haveA = full(q, U);
+        if (haveA) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) A[u] = *reinterpret_cast<const uint4 *>(src + (q + u * stride) * 8);
+            q += U * stride;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) hist_add8(h, B[u]);
+    }
+    for (; full(q, 1); q += stride) hist_add8(h, *reinterpret_cast<const uint4 *>(src + q * 8));
     for (; q < noct; q += stride) {
         const uint4 v = *reinterpret_cast<const uint4 *>(src + q * 8);
         const unsigned int w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            atomicAdd(&h[bin_slot(w[k] & 0xffffu)], 1u);
-            atomicAdd(&h[bin_slot(w[k] >> 16)], 1u);
+            atomicAdd(&h[kHistCopies * bin_slot(w[k] & 0xffffu)], 1u);
+            atomicAdd(&h[kHistCopies * bin_slot(w[k] >> 16)], 1u);
         }
     }
     for (long i = noct * 8 + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n_per_ch; i += stride)
-        atomicAdd(&h[bin_slot(src[i])], 1u);
+        atomicAdd(&h[kHistCopies * bin_slot(src[i])], 1u);
     __syncthreads();
     CountT *dst = counts + ((long)l * C + c) * T;
     for (int i = threadIdx.x; i < T; i += blockDim.x) {
-        const unsigned int sl = bin_slot(i);
-        unsigned int v = 0;
-#pragma unroll
-        for (int k = 0; k < kHistCopies; ++k) v += h[k * kHistCopyStride + sl];
+        const uint4 q4 = reinterpret_cast<const uint4 *>(h)[bin_slot(i)];
+        const unsigned int v = (q4.x + q4.y) + (q4.z + q4.w);
         if (v) atomicAdd(&dst[i], (CountT)v);
     }
 }
