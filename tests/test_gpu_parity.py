@@ -160,7 +160,7 @@ def test_quantize_duplicate_code_points(ops):
     assert np.array_equal(host(got_i), want_i[:, :, 0])
 
 
-@pytest.mark.parametrize("Nbits", [4, 6, 8])
+@pytest.mark.parametrize("Nbits", [4, 5, 6, 7, 8, 9])
 def test_quantize_other_bit_depths(ops, Nbits):
     rng = np.random.default_rng(Nbits)
     orc = O.ChannelwiseOracle(2, Nbits)
@@ -304,3 +304,22 @@ def test_fast_kernel_tie_machinery():
     assert rc1 == 0, out1
     rc2, out2 = run(2)
     assert rc2 == 1 and "mismatches 0\n" not in out2.splitlines()[-1] + "\n", out2
+
+
+@pytest.mark.parametrize("Nbits", [5, 7, 9])
+def test_notebook_and_histogram_other_bit_depths(ops, Nbits):
+    rng = np.random.default_rng(40 + Nbits)
+    means = rng.normal(-0.08, 1.23, 3001).astype(np.float32)
+    stds = np.exp(rng.normal(-2, 0.7, 3001)).astype(np.float32)
+    pts, lens = O.notebook_code_book(O.empirical_std(means), Nbits)
+    betas = [0.02, 1.0, 250.0]
+    idx, val = ops.quantize_notebook(dev(means), dev(stds), dev(pts), betas, N=Nbits)
+    rank_of_slot = O.level_major_to_rank(Nbits)
+    for i, b in enumerate(betas):
+        v, slot = CO.compress_coordinates(means, stds, b, pts, lens, threads=4)
+        assert np.array_equal(host(val)[i], v)
+        assert np.array_equal(host(idx)[i].astype(np.int64), rank_of_slot[slot])
+    Tn = 2 ** (Nbits + 1) - 1
+    want = CO.histogram(host(idx)[:, :, None], 1, N=Nbits)
+    got = host(ops.histogram(idx, 1, N=Nbits))
+    assert got.shape == (3, 1, Tn) and np.array_equal(got, want)

@@ -377,11 +377,14 @@ int histogram_entry(const char *who, const uint16_t *d_idx, int64_t n_rows, int3
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     switch (N) {
         case 10: return launch_hist<10, CountT>(d_idx, n_rows, n_ch, layout, n_lambda, cnt, st);
+        case 9: return launch_hist<9, CountT>(d_idx, n_rows, n_ch, layout, n_lambda, cnt, st);
         case 8: return launch_hist<8, CountT>(d_idx, n_rows, n_ch, layout, n_lambda, cnt, st);
+        case 7: return launch_hist<7, CountT>(d_idx, n_rows, n_ch, layout, n_lambda, cnt, st);
         case 6: return launch_hist<6, CountT>(d_idx, n_rows, n_ch, layout, n_lambda, cnt, st);
+        case 5: return launch_hist<5, CountT>(d_idx, n_rows, n_ch, layout, n_lambda, cnt, st);
         case 4: return launch_hist<4, CountT>(d_idx, n_rows, n_ch, layout, n_lambda, cnt, st);
         default:
-            set_error("%s: max_bits_per_coord N=%d not built (have 4, 6, 8, 10)", who, N);
+            set_error("%s: max_bits_per_coord N=%d not built (have 4 ... 10)", who, N);
             return VBQ_ERR_UNSUPPORTED;
     }
 }

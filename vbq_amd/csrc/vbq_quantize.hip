@@ -444,11 +444,14 @@ extern "C" int vbq_quantize_f32(const float *d_mu, const float *d_sigma, int64_t
                                                  d_workspace, st);
     switch (N) {
         VBQ_DISPATCH_N(10)
+        VBQ_DISPATCH_N(9)
         VBQ_DISPATCH_N(8)
+        VBQ_DISPATCH_N(7)
         VBQ_DISPATCH_N(6)
+        VBQ_DISPATCH_N(5)
         VBQ_DISPATCH_N(4)
         default:
-            set_error("vbq_quantize_f32: max_bits_per_coord N=%d not built (have 4, 6, 8, 10)", N);
+            set_error("vbq_quantize_f32: max_bits_per_coord N=%d not built (have 4 ... 10)", N);
             return VBQ_ERR_UNSUPPORTED;
     }
 #undef VBQ_DISPATCH_N

@@ -516,6 +516,12 @@ template int launch_quant_fast<10>(const float *, const float *, int64_t, int32_
                                    const float *, int32_t, uint16_t *, float *, float *, int64_t, int, hipStream_t);
 template int launch_quant_fast<8>(const float *, const float *, int64_t, int32_t, const float *, const float *,
                                   const float *, int32_t, uint16_t *, float *, float *, int64_t, int, hipStream_t);
+template int launch_quant_fast<9>(const float *, const float *, int64_t, int32_t, const float *, const float *,
+                                  const float *, int32_t, uint16_t *, float *, float *, int64_t, int, hipStream_t);
+template int launch_quant_fast<7>(const float *, const float *, int64_t, int32_t, const float *, const float *,
+                                  const float *, int32_t, uint16_t *, float *, float *, int64_t, int, hipStream_t);
+template int launch_quant_fast<5>(const float *, const float *, int64_t, int32_t, const float *, const float *,
+                                  const float *, int32_t, uint16_t *, float *, float *, int64_t, int, hipStream_t);
 template int launch_quant_fast<6>(const float *, const float *, int64_t, int32_t, const float *, const float *,
                                   const float *, int32_t, uint16_t *, float *, float *, int64_t, int, hipStream_t);
 template int launch_quant_fast<4>(const float *, const float *, int64_t, int32_t, const float *, const float *,
