@@ -13,6 +13,7 @@ from oracle import vbq_oracle as O
 
 pytestmark = pytest.mark.gpu
 N = 10
+T = 2 ** (N + 1) - 1
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -308,3 +309,26 @@ def test_transpose_scalar_and_vector_paths(rows, cols):
     x = rng.normal(size=(rows, cols)).astype(np.float32)
     got = ops.transpose(torch.from_numpy(x).cuda()).cpu().numpy()
     assert got.shape == (cols, rows) and np.array_equal(got, x.T)
+
+
+def test_model_table_cache_follows_replaced_models(golden):
+    """The device copies of the entropy-model tables are cached across compress_latents calls and must be rebuilt
+    when a model array is replaced (assigning a new array, or a whole new dict)."""
+    g, q, _ = _case(golden)
+    rng = np.random.default_rng(12)
+    C = q.num_channels
+    means = rng.normal(0, 1, (1, 6, 5, C)).astype(np.float32)
+    logvars = rng.normal(-4, 0.5, (1, 6, 5, C)).astype(np.float32)
+    lambs = [0.1, 2.0]
+    q.raw_code_length_entropy_models = None
+    q.entropy_models = {l: rng.uniform(1, 12, (C, T)).astype(np.float32) for l in lambs}
+    a = q.compress_latents(means, logvars, lambs)
+    b = q.compress_latents(means, logvars, lambs)                     # served from the cache
+    assert all(np.array_equal(a["num_bits"][l], b["num_bits"][l]) for l in lambs)
+    q.entropy_models[lambs[1]] = q.entropy_models[lambs[1]] + np.float32(1.0)     # a new array under the same key
+    c = q.compress_latents(means, logvars, lambs)
+    assert np.array_equal(c["num_bits"][lambs[0]], a["num_bits"][lambs[0]])
+    assert np.array_equal(c["num_bits"][lambs[1]], a["num_bits"][lambs[1]] + np.float32(1.0))
+    q.entropy_models = {l: np.zeros((C, T), np.float32) for l in lambs}
+    d = q.compress_latents(means, logvars, lambs)
+    assert all(not d["num_bits"][l].any() for l in lambs)

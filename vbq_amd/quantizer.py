@@ -190,17 +190,34 @@ class ChannelwisePriorCDFQuantizer:
         # channel-major planes [C, B]
         return ops.transpose(mu.contiguous()), ops.transpose(sg.contiguous())
 
+    def _keyed_dev(self, name: str, arrays, builder):
+        """Device copy of a table assembled from per-lambda model arrays, rebuilt only when one of those arrays is
+        replaced.  Keyed on the arrays' identities; the cache entry holds the arrays, so an id cannot be reused by a
+        new object while the entry lives.  (Editing a model array in place is not detected.)"""
+        arrays = list(arrays)
+        hit = self._dev_cache.get(name)
+        if (hit is not None and len(hit[0]) == len(arrays) and all(a is b for a, b in zip(hit[0], arrays))
+                and hit[1].device == self.device):
+            return hit[1]
+        t = builder().to(self.device)
+        self._dev_cache[name] = (arrays, t)
+        return t
+
     def _level_len_dev(self, lambs) -> Optional[torch.Tensor]:
         """quantizer.py:166,171-175: None for raw lengths, else f32 [L, C, N+1] = n + overhead."""
         if not self.raw_code_length_entropy_models:
             return None
+        arrays = [self.raw_code_length_entropy_models[lamb] for lamb in lambs]      # KeyError as in the reference
+        return self._keyed_dev("level_len", arrays, lambda: self._level_len_host(lambs))
+
+    def _level_len_host(self, lambs) -> torch.Tensor:
         N = self.max_bits_per_coord
         lv = np.arange(N + 1, dtype=np.int32).astype(np.float32)
         rows = []
         for lamb in lambs:
             model = np.asarray(self.raw_code_length_entropy_models[lamb])            # C x (N+1), KeyError as in the reference
             rows.append(lv[None, :].astype(model.dtype) + model)
-        return torch.from_numpy(np.stack(rows).astype(np.float32)).to(self.device)
+        return torch.from_numpy(np.stack(rows).astype(np.float32))
 
     def _solve_idx(self, mu_cb, sg_cb, lambs, level_len):
         """u16 rank indices [L, C, B] on the device."""
@@ -309,15 +326,19 @@ class ChannelwisePriorCDFQuantizer:
         else:
             tab = torch.gather(level_len, 2, lev.expand(len(lambs), C, -1)).contiguous()
             raw_bits = ops.gather(idx, tab, C, N=N, layout="cb", out_layout="bc")
-        models = np.stack([np.asarray(self.entropy_models[lamb]) for lamb in lambs]).astype(np.float32)   # [L, C, T]
-        if not self._strict:       # the reference indexes with the canonical qidx; same value either way once
-            models = np.stack([np.take_along_axis(mm, self._canon, axis=1) for mm in models])            # mapped per rank
-        num_bits = ops.gather(idx, torch.from_numpy(models).to(self.device), C, N=N, layout="cb",
-                              out_layout="bc")                                                           # :226-228
+        def models_host():
+            models = np.stack([np.asarray(self.entropy_models[lamb]) for lamb in lambs]).astype(np.float32)   # [L, C, T]
+            if not self._strict:   # the reference indexes with the canonical qidx; same value either way once
+                models = np.stack([np.take_along_axis(mm, self._canon, axis=1) for mm in models])        # mapped per rank
+            return torch.from_numpy(models)
+        models_dev = self._keyed_dev("entropy_models", [self.entropy_models[lamb] for lamb in lambs], models_host)
+        num_bits = ops.gather(idx, models_dev, C, N=N, layout="cb", out_layout="bc")                     # :226-228
         out_keys = ("Z_hat", "raw_num_bits", "num_bits_cl", "num_bits")
         output = {key: dict() for key in out_keys}
         for i, lamb in enumerate(lambs):
             def to_latent_shape(t):
+                # one device-to-host copy per (quantity, lambda): ~1.5 MB pieces recycle the allocator's warm pages,
+                # a single 50 MB copy per quantity page-faults its fresh destination and measured 4x slower
                 return t.cpu().numpy().reshape(shape)                               # B x C -> latent shape (:237)
             output["Z_hat"][lamb] = to_latent_shape(zhat[i])
             output["raw_num_bits"][lamb] = to_latent_shape(raw_bits[i])
