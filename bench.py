@@ -141,6 +141,10 @@ def main():
     cdtype = torch.int32 if rows * world < 2 ** 31 else torch.int64
     counts2 = [torch.zeros((L, C, T), dtype=cdtype, device=dev) for _ in range(2)]
     works = [None, None]
+    reducers = None
+    if world > 1:
+        from vbq_amd.dist import CountsAllReduce
+        reducers = [CountsAllReduce(L * C * T, dev, max_global_count=rows * world) if cdtype == torch.int32 else None for _ in range(2)]
     ws = torch.empty(ops._lib.lib().vbq_quantize_workspace_bytes(C, L, N_BITS), dtype=torch.uint8, device=dev)
 
     # setup (untimed): pass 1 with raw lengths -> bit-length histogram -> corrected lengths (quantizer.py:96-112)
@@ -178,7 +182,8 @@ def main():
                 evh[i][1].record()
             if world > 1:
                 # asynchronous: the collective of step i overlaps the kernels of step i+1 (two buffers)
-                works[slot] = dist.all_reduce(counts, async_op=True)
+                # (three 21-bit counters per int64 word on the wire while the global counts allow it)
+                works[slot] = reducers[slot].start(counts) if reducers[slot] is not None else dist.all_reduce(counts, async_op=True)
 
     def drain():
         for b in range(2):

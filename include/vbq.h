@@ -228,6 +228,15 @@ int vbq_rans_decode_u16(const uint16_t *d_words, const uint32_t *d_sizes, int64_
                         int32_t N, int32_t seg, const uint16_t *d_freq, uint16_t *d_idx, void *stream);
 
 /* ----------------------------------------------------------------------------------
+ * Packed counters for the histogram all-reduce: three 21-bit fields per int64 word.
+ * An integer SUM all-reduce of the words adds the fields independently while every GLOBAL count is
+ * below 2^21 (the caller checks: global rows per channel < 2097152), at 2.67 instead of 4 bytes per
+ * bin on the wire.  n bins <-> (n + 2) / 3 words.
+ * ---------------------------------------------------------------------------------- */
+int vbq_pack_counts_3x21(const int32_t *d_counts, int64_t n, int64_t *d_words, void *stream);
+int vbq_unpack_counts_3x21(const int64_t *d_words, int64_t n, int32_t *d_counts, void *stream);
+
+/* ----------------------------------------------------------------------------------
  * Comparison quantizers (img-compression/quantizer.py:259-333).
  *   vbq_uniform_quantize_f32  I = clip(floor((x - min) / delta), 0, levels-1) in f32 (:280,295),
  *                             value = offset + delta * I (:297); I is returned as f32 like the

@@ -69,3 +69,77 @@ def test_sharded_entropy_models_equal_single_process():
         for l in LAMBS:
             assert np.array_equal(raw[l], ref.raw_code_length_entropy_models[l])
             assert np.array_equal(full[l], ref.entropy_models[l])
+
+
+def test_pack_counts_round_trip_and_field_sums():
+    """vbq_pack_counts_3x21: unpack(pack(c)) == c for ragged sizes, and the SUM of packed words is the field-wise
+    sum while every total stays below 2^21 (what the all-reduce relies on)."""
+    if not torch.cuda.is_available():
+        pytest.fail("gpu-marked test run without a ROCm device")
+    from vbq_amd import _lib, ops
+    h = _lib.lib()
+    rng = np.random.default_rng(3)
+    for n in (1, 2, 3, 4, 1000, 3 * 2047 + 1):
+        parts = [torch.from_numpy(rng.integers(0, (1 << 21) // 8, n).astype(np.int32)).cuda() for _ in range(8)]
+        parts[0][0] = (1 << 21) // 8 - 1
+        words = []
+        for c in parts:
+            w = torch.empty((n + 2) // 3, dtype=torch.int64, device="cuda")
+            _lib.check(h.vbq_pack_counts_3x21(ops._ptr(c), n, ops._ptr(w), ops._stream(c)), "pack")
+            back = torch.empty_like(c)
+            _lib.check(h.vbq_unpack_counts_3x21(ops._ptr(w), n, ops._ptr(back), ops._stream(c)), "unpack")
+            assert torch.equal(back, c)
+            words.append(w)
+        total = torch.stack(words).sum(0)
+        out = torch.empty(n, dtype=torch.int32, device="cuda")
+        _lib.check(h.vbq_unpack_counts_3x21(ops._ptr(total), n, ops._ptr(out), ops._stream(out)), "unpack")
+        assert torch.equal(out, torch.stack(parts).sum(0).to(torch.int32))
+
+
+def _reduce_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from vbq_amd.dist import CountsAllReduce
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(100 + rank)
+    res = []
+    for limit in (1000, 1 << 22):                                   # packed and plain int32 paths
+        c = torch.from_numpy(rng.integers(0, 400, (3, 4, 2047)).astype(np.int32)).to(dev)
+        red = CountsAllReduce(c.numel(), dev, max_global_count=limit)
+        red.start(c).wait()
+        torch.cuda.synchronize()
+        res.append((red.packed, c.cpu().numpy()))
+    out.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_counts_all_reduce_packed_equals_plain():
+    if not torch.cuda.is_available():
+        pytest.fail("gpu-marked test run without a ROCm device")
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = 29800 + os.getpid() % 150
+    procs = [ctx.Process(target=_reduce_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(out.get(timeout=240) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    want = []
+    for i in range(2):
+        gens = [np.random.default_rng(100 + r) for r in range(2)]
+        arrs = []
+        for g in gens:
+            a = [g.integers(0, 400, (3, 4, 2047)).astype(np.int32) for _ in range(2)]
+            arrs.append(a[i])
+        want.append(arrs[0] + arrs[1])
+    for r in range(2):
+        assert res[r][0][0] is True and res[r][1][0] is False
+        for i in range(2):
+            assert np.array_equal(res[r][i][1], want[i])

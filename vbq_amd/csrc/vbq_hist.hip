@@ -403,6 +403,63 @@ extern "C" int vbq_histogram_u16_i32(const uint16_t *d_idx, int64_t n_rows, int3
                                               reinterpret_cast<unsigned int *>(d_counts), stream);
 }
 
+// ---------------------------------------------------------------------------- packed counters for the all-reduce
+// Three 21-bit counters per int64 word: an integer SUM all-reduce of the words adds the three fields
+// independently as long as every global count stays below 2^21 (no carry between fields), and moves
+// 2.67 instead of 4 bytes per bin over xGMI.  n bins -> ceil(n / 3) words; missing fields are zero.
+namespace vbq {
+namespace {
+__global__ void __launch_bounds__(256)
+k_pack3x21(const int32_t *__restrict__ c, long n, long nw, unsigned long long *__restrict__ w) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nw; i += (long)gridDim.x * blockDim.x) {
+        const long b = 3 * i;
+        const unsigned long long f0 = (unsigned int)c[b];
+        const unsigned long long f1 = b + 1 < n ? (unsigned int)c[b + 1] : 0u;
+        const unsigned long long f2 = b + 2 < n ? (unsigned int)c[b + 2] : 0u;
+        w[i] = f0 | (f1 << 21) | (f2 << 42);
+    }
+}
+__global__ void __launch_bounds__(256)
+k_unpack3x21(const unsigned long long *__restrict__ w, long n, long nw, int32_t *__restrict__ c) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nw; i += (long)gridDim.x * blockDim.x) {
+        const unsigned long long v = w[i];
+        const long b = 3 * i;
+        c[b] = (int32_t)(v & 0x1fffffu);
+        if (b + 1 < n) c[b + 1] = (int32_t)((v >> 21) & 0x1fffffu);
+        if (b + 2 < n) c[b + 2] = (int32_t)((v >> 42) & 0x1fffffu);
+    }
+}
+}  // namespace
+}  // namespace vbq
+
+extern "C" int vbq_pack_counts_3x21(const int32_t *d_counts, int64_t n, int64_t *d_words, void *stream) {
+    using namespace vbq;
+    VBQ_REQUIRE(n >= 0, VBQ_ERR_INVALID_ARGUMENT, "vbq_pack_counts_3x21: n < 0");
+    if (n == 0) return VBQ_OK;
+    VBQ_REQUIRE(d_counts && d_words, VBQ_ERR_INVALID_ARGUMENT, "vbq_pack_counts_3x21: null pointer");
+    const int64_t nw = (n + 2) / 3;
+    int64_t gx = (nw + 255) / 256;
+    if (gx > 8192) gx = 8192;
+    hipLaunchKernelGGL(k_pack3x21, dim3((unsigned)gx), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), d_counts, (long)n, (long)nw,
+                       reinterpret_cast<unsigned long long *>(d_words));
+    VBQ_CHECK_LAUNCH("pack_counts");
+    return VBQ_OK;
+}
+
+extern "C" int vbq_unpack_counts_3x21(const int64_t *d_words, int64_t n, int32_t *d_counts, void *stream) {
+    using namespace vbq;
+    VBQ_REQUIRE(n >= 0, VBQ_ERR_INVALID_ARGUMENT, "vbq_unpack_counts_3x21: n < 0");
+    if (n == 0) return VBQ_OK;
+    VBQ_REQUIRE(d_counts && d_words, VBQ_ERR_INVALID_ARGUMENT, "vbq_unpack_counts_3x21: null pointer");
+    const int64_t nw = (n + 2) / 3;
+    int64_t gx = (nw + 255) / 256;
+    if (gx > 8192) gx = 8192;
+    hipLaunchKernelGGL(k_unpack3x21, dim3((unsigned)gx), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<const unsigned long long *>(d_words), (long)n, (long)nw, d_counts);
+    VBQ_CHECK_LAUNCH("unpack_counts");
+    return VBQ_OK;
+}
+
 extern "C" int vbq_moments_f32(const float *d_x, int64_t n_rows, int32_t n_ch, int32_t layout, double *d_out,
                                void *stream) {
     using namespace vbq;

@@ -72,3 +72,47 @@ def entropy_models_from_local_counts(local_counts: torch.Tensor, N: int, add_n_s
     raw = entropy.neg_log2_freq(entropy.level_counts_from_counts(g, N), add_n_smoothing)
     full = entropy.neg_log2_freq(g, add_n_smoothing)
     return raw, full
+
+
+PACKED_FIELD_LIMIT = 1 << 21
+
+
+class CountsAllReduce:
+    """SUM all-reduce of an int32 histogram [L, C, T] with fewer bytes on the wire.
+
+    While every global count is below 2^21 (global rows per channel < 2 097 152) three counters travel in one
+    int64 word (vbq_pack_counts_3x21): the SUM of the words is the field-wise sum, 2.67 instead of 4 bytes per
+    bin -- the difference between a communication-bound and a compute-bound step on two GPUs joined by a single
+    xGMI link.  Otherwise the int32 tensor is reduced as it is.  `start()` is asynchronous (the collective
+    overlaps later kernels); `wait()` leaves the global counts in the tensor given to `start()`.
+    """
+
+    def __init__(self, numel: int, device, max_global_count: int, group=None):
+        self.group = group
+        self.packed = max_global_count < PACKED_FIELD_LIMIT and device.type == "cuda"
+        self.words = torch.empty((numel + 2) // 3, dtype=torch.int64, device=device) if self.packed else None
+        self._work = None
+        self._counts = None
+
+    def start(self, counts: torch.Tensor):
+        from . import _lib, ops
+        assert counts.dtype == torch.int32 and counts.is_contiguous()
+        self._counts = counts
+        if self.packed:
+            _lib.check(_lib.lib().vbq_pack_counts_3x21(ops._ptr(counts), counts.numel(), ops._ptr(self.words), ops._stream(counts)),
+                       "vbq_pack_counts_3x21")
+            self._work = dist.all_reduce(self.words, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            self._work = dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        return self
+
+    def wait(self):
+        from . import _lib, ops
+        if self._work is None:
+            return
+        self._work.wait()                 # the compute stream now waits for the collective
+        if self.packed:
+            c = self._counts
+            _lib.check(_lib.lib().vbq_unpack_counts_3x21(ops._ptr(self.words), c.numel(), ops._ptr(c), ops._stream(c)),
+                       "vbq_unpack_counts_3x21")
+        self._work = None
