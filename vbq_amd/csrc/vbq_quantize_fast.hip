@@ -43,16 +43,8 @@ constexpr int kFastThreads = 256;
 #ifndef VBQ_FAST_WAVES
 #define VBQ_FAST_WAVES 4
 #endif
-#ifndef VBQ_FAST_PRUNE
-#define VBQ_FAST_PRUNE 0      // 1: skip groups of deep levels no lane of the wave can still win (exact).  On the
-                              // bench data a wave executes 8.2 of 11 levels on average, but hipcc's code for the
-                              // branchy form is 20 % slower than the straight-line form; kept for hand-tuning later.
-#endif
 #ifndef VBQ_SLOW_INLINE
 #define VBQ_SLOW_INLINE __noinline__
-#endif
-#ifndef VBQ_FAST_PKMASK
-#define VBQ_FAST_PKMASK 0     // equality mask by v_sub + v_alignbit (0) or by packed FMAs (1: measured 6 % slower)
 #endif
 constexpr int kFastNE = VBQ_FAST_NE;      // elements per thread: 4 (16-B loads) or 2 (8-B loads)
 
@@ -72,44 +64,6 @@ __device__ __forceinline__ float dist_cost(float P, float mu, double rinv) {
 }
 
 __device__ __forceinline__ float min3f(float a, float b, float c) { return fminf(fminf(a, b), c); }
-
-// Packed-f32 helpers (one VOP3P instruction handles the two elements of a thread; v_pk_fma_f32
-// issues in 4 cycles per wave64 = 2 cycles per FMA, the cheapest arithmetic on the chip).
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-// clamp(a * b + c) to [0, 1], per half
-__device__ __forceinline__ f32x2 pk_fma_clamp01(f32x2 a, f32x2 b, f32x2 c) {
-    f32x2 d;
-    asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-    return d;
-}
-
-// a * b + c, per half (exact for the small integers it is used on)
-__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) {
-    f32x2 d;
-    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-    return d;
-}
-
-// Bit mask sum_n ind[n] * 2^n of M 0/1 indicators as a balanced tree of packed FMAs (depth
-// ceil(log2 M) instead of a serial Horner chain; the weights 2^(2^j) live in registers).
-template <int M>
-__device__ __forceinline__ f32x2 pk_bitmask(f32x2 (&v)[M]) {
-    int m = M;
-    float w = 2.0f;
-#pragma unroll
-    for (int pass = 0; pass < 5; ++pass) {
-        if (m <= 1) break;
-        const f32x2 w2 = {w, w};
-        int o = 0;
-#pragma unroll
-        for (int i = 0; i + 1 < m; i += 2) v[o++] = pk_fma(v[i + 1], w2, v[i]);
-        if (m & 1) v[o++] = v[m - 1];
-        m = o;
-        w = w * w;
-    }
-    return v[0];
-}
 
 // Minimum of M values as a tree of v_min3_f32 (ceil((M-1)/2) instructions).
 template <int M>
@@ -202,9 +156,7 @@ k_quant_fast(const float *__restrict__ mu, const float *__restrict__ sg, long n_
     // dbg (tests only, VBQ_FAST_DEBUG): 1 = send every solve through the literal scan,
     // 2 = never flag (shows that the flags are what keeps the fast path exact)
     const bool force_slow = dbg == 1, never_flag = dbg == 2;
-    constexpr int GL = 3;                             // levels per pruning group
-    constexpr int NG = (N1 + GL - 1) / GL;            // groups: levels [3g, 3g+3)
-    constexpr int PS = (N1 + NG + 3) & ~3;            // penalty row: N1 penalties, NG-1 suffix minima, padding
+    constexpr int PS = (N1 + 3) & ~3;                 // penalty row, padded to whole 16-byte LDS reads
     __shared__ float tb[T + 1];
     __shared__ uint32_t scratch[N1 * NE * kFastThreads];
     __shared__ __align__(16) float penl[kMaxLambdaChunk * PS];
@@ -213,15 +165,6 @@ k_quant_fast(const float *__restrict__ mu, const float *__restrict__ sg, long n_
     for (int i = threadIdx.x; i < L * PS; i += blockDim.x) {
         const int l = i / PS, n = i - l * PS;
         penl[i] = n < N1 ? pen[((long)l * C + c) * N1 + n] : 0.0f;
-    }
-    __syncthreads();
-    if (threadIdx.x < L) {      // penl[l][N1 + g] = min over levels >= 3(g+1) of the penalty (a cost there is >= it)
-        float *row = penl + threadIdx.x * PS;
-        float m = __builtin_inff();
-        for (int n = N1 - 1; n >= GL; --n) {
-            m = fminf(m, row[n]);
-            if (n % GL == 0) row[N1 + n / GL - 1] = m;
-        }
     }
     __syncthreads();
 
@@ -316,81 +259,13 @@ k_quant_fast(const float *__restrict__ mu, const float *__restrict__ sg, long n_
             float cst[NE][N1];
             float S[NE];
             uint32_t ne[NE];                                    // bit n set <=> cost_n != S
-#if VBQ_FAST_PRUNE
-            // Levels are taken in groups of three.  After a group, if for EVERY lane of the wave the best
-            // cost so far is strictly below the smallest penalty of all deeper levels, no deeper candidate
-            // can reach it (cost >= penalty since the distortion is >= 0): the wave skips them for this
-            // lambda, and their mask bits are preset to "differs".  Exact, not a heuristic.
-            int ngroups = NG;                                   // wave-uniform
-#pragma unroll
-            for (int gI = 0; gI < NG; ++gI) {
-                if (gI < ngroups) {
-                    constexpr int dummy = 0; (void)dummy;
-                    const int n0 = gI * GL;
-#pragma unroll
-                    for (int n = n0; n < n0 + GL && n < N1; ++n)
-#pragma unroll
-                        for (int k = 0; k < NE; ++k) cst[k][n] = __fadd_rn(du[k][n], p[n]);
-#pragma unroll
-                    for (int k = 0; k < NE; ++k) {
-                        float m = cst[k][n0];
-                        if (n0 + 2 < N1) m = min3f(m, cst[k][n0 + 1], cst[k][n0 + 2]);
-                        else if (n0 + 1 < N1) m = fminf(m, cst[k][n0 + 1]);
-                        S[k] = gI == 0 ? m : fminf(S[k], m);
-                    }
-                    if (gI + 1 < NG) {
-                        const float bound = pp[N1 + gI];
-                        bool done = true;
-#pragma unroll
-                        for (int k = 0; k < NE; ++k) done = done && (S[k] < bound);
-                        if (__all(done)) ngroups = gI + 1;
-                    }
-                }
-            }
-            {
-                const int nlev = ngroups * GL < N1 ? ngroups * GL : N1;
-                const uint32_t init = (1u << (N1 - nlev)) - 1u;     // skipped levels: "differs"
-#pragma unroll
-                for (int k = 0; k < NE; ++k) ne[k] = init;
-            }
-#pragma unroll
-            for (int gI = NG - 1; gI >= 0; --gI) {
-                if (gI < ngroups) {
-                    const int n0 = gI * GL;
-#pragma unroll
-                    for (int n = (n0 + GL < N1 ? n0 + GL : N1) - 1; n >= n0; --n)
-#pragma unroll
-                        for (int k = 0; k < NE; ++k)
-                            ne[k] = __builtin_amdgcn_alignbit(ne[k], __float_as_uint(__fsub_rn(S[k], cst[k][n])), 31);
-                }
-            }
-#else
 #pragma unroll
             for (int n = 0; n < N1; ++n)
 #pragma unroll
                 for (int k = 0; k < NE; ++k) cst[k][n] = __fadd_rn(du[k][n], p[n]);
 #pragma unroll
             for (int k = 0; k < NE; ++k) S[k] = min_of<N1>(cst[k]);
-            if constexpr (NE == 2 && VBQ_FAST_PKMASK) {
-                // ind_n = clamp((c_n - S) * 2^64) is exactly 0 where c_n == S and exactly 1 elsewhere:
-                // scaling by a power of two commutes with the rounding of c_n - S; a non-zero difference is
-                // >= ulp(S) >= 2^-64 when S >= 2^-40, and when S < 2^-40 the winner is level 0 and every
-                // other level costs >= lambda * 1 >= 2^-39 (the launcher routes smaller lambdas to the plain
-                // kernel).  Overflow gives +inf -> 1; S >= 2^64 gives NaN -> a mask the popcount test flags.
-                // mask = sum_n ind_n * 2^n by a tree of packed FMAs, exact in f32.
-                const float H = 18446744073709551616.0f;        // 2^64
-                const f32x2 H2 = {H, H};
-                const f32x2 nSH = {-(S[0] * H), -(S[1] * H)};
-                f32x2 ind[N1];
-#pragma unroll
-                for (int n = 0; n < N1; ++n) {
-                    const f32x2 c2 = {cst[0][n], cst[1][n]};
-                    ind[n] = pk_fma_clamp01(c2, H2, nSH);
-                }
-                const f32x2 acc = pk_bitmask<N1>(ind);
-                ne[0] = (uint32_t)acc.x;
-                ne[1] = (uint32_t)acc.y;
-            } else {
+            {
 #pragma unroll
                 for (int k = 0; k < NE; ++k) ne[k] = 0;
 #pragma unroll
@@ -399,7 +274,6 @@ k_quant_fast(const float *__restrict__ mu, const float *__restrict__ sg, long n_
                     for (int k = 0; k < NE; ++k)
                         ne[k] = __builtin_amdgcn_alignbit(ne[k], __float_as_uint(__fsub_rn(S[k], cst[k][n])), 31);
             }
-#endif
             uint32_t pk[NE];
 #pragma unroll
             for (int k = 0; k < NE; ++k) {
