@@ -159,3 +159,21 @@ def test_evaluate_compression_quantizer(tmp_path):
     assert res["B"][1, 0] == np.sum(out["num_bits"][lambs[0]])
     with pytest.raises(Exception):
         utils.evaluate_compression_quantizer(q, vae, files, lambs, use_tf=True)
+
+
+def test_beta_sweep_equals_single_betas():
+    """E.test_betas (all betas in one K1n / K2 launch) == the notebook's per-beta test_beta, row by row."""
+    _need_gpu()
+    from vbq_amd import embeddings as E
+    rng = np.random.default_rng(21)
+    V, K = 1500, 40
+    means = rng.normal(0, 1, (V, K)).astype(np.float32)
+    stds = np.exp(rng.normal(-2, 0.5, (V, K))).astype(np.float32)
+    an = rng.integers(0, V, (300, 4)).astype(np.int32)
+    cp, _ = E.make_code_book(E.empirical_std(means))
+    betas = [0.01, 1.0, 50.0, 1e4]
+    sweep = E.test_betas(means, stds, betas, cp, an)
+    assert sweep.shape == (4, 4)
+    for i, b in enumerate(betas):
+        assert np.array_equal(sweep[i], np.array(E.test_beta(means, stds, b, cp, analogies_id=an), dtype=np.float64))
+    assert np.all(np.diff(sweep[:, 3]) < 0)                       # the rate falls as beta grows

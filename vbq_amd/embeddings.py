@@ -6,7 +6,7 @@
     compress_coordinates(means, stds, beta, ...) ipynb:429-443   (K1n)
     empirical_entropy(values)                    ipynb:452-455   (K2 histogram when indices are given)
     prediction_ranks(emb, analogies_id)          ipynb:199-209   (fused f32 MFMA GEMM + count, vbq_ranks.hip)
-    test_beta / quantize_coordinates / test_quantization   ipynb:464-473, cells 36-37
+    test_beta / test_betas / quantize_coordinates / test_quantization   ipynb:464-473, cells 32, 36-37
 """
 from __future__ import annotations
 
@@ -152,6 +152,20 @@ def test_quantization(means, quantization_max, analogies_id):
     bz_bits = len(bz2.compress(raw, 9)) * 8
     lz_bits = len(lzma.compress(raw, format=lzma.FORMAT_ALONE, preset=9)) * 8
     return mrr, acc, hits10, bits, gz_bits, bz_bits, lz_bits
+
+
+def test_betas(means, stds, betas: Sequence[float], codepoints, analogies_id):
+    """The notebook's sweep `[test_beta(vecs_u, stds_u, beta) for beta in betas]` (ipynb cell 32) with the work
+    batched the way the device wants it: one K1n launch solves every beta, one K2 launch counts every beta's
+    indices, then one fused rank GEMM per beta.  Returns float64 [n_beta, 4] = (mrr, acc, hits10, bits) rows."""
+    idx, val = compress_coordinates_sweep(means, stds, betas, codepoints)
+    bits = entropy_from_indices(idx, N=int(np.log2(len(codepoints) + 1)) - 1)
+    shape = tuple(np.shape(means))
+    rows = []
+    for i in range(len(betas)):
+        ranks = prediction_ranks(val[i].reshape(shape), analogies_id)
+        rows.append(analogy_metrics(ranks) + (bits[i],))
+    return np.array(rows, dtype=np.float64)
 
 
 def test_beta(means, stds, beta, codepoints, analogies_id=None):
