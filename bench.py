@@ -81,6 +81,36 @@ def cpu_baseline(mu, sigma, tables, level_len, target_s=12.0):
                       f"(oracle/vbq_oracle.c, OpenMP {threads} threads), solve only, {dt:.1f} s"}, idx, n
 
 
+def cpu_baseline_numpy(mu, sigma, tables, level_len, idx_check, target_s=5.0, max_rows=2048):
+    """The reference's own formulation in NumPy (per-level searchsorted on padded grids, 21 x B x C candidate
+    tensors, per-lambda argmax: oracle/vbq_oracle.py restating quantizer.py:65-80,156-188 and utils.py:363-423;
+    golden vectors G5/G6/G8 tie it to the reference's code), single process, NumPy's default threading."""
+    from oracle import vbq_oracle as O
+    rows, C = mu.shape
+    L = len(LAMBDAS)
+    orc = O.ChannelwiseOracle(C, N_BITS)
+    orc.build_code_points(lambda xi: tables.T)
+    if level_len is not None:
+        lv = np.arange(N_BITS + 1, dtype=np.float32)
+        orc.raw_models = {lam: level_len[i] - lv[None, :] for i, lam in enumerate(LAMBDAS)}
+    n = max(1, min(rows, 64))
+    t0 = time.perf_counter()
+    orc.compress_batch(mu[:n], sigma[:n], LAMBDAS)
+    rate = n * C * L / (time.perf_counter() - t0)
+    n = int(max(n, min(rows, max_rows, target_s * rate / (C * L))))      # the 21 x B x C x L length stack bounds B
+    t0 = time.perf_counter()
+    Z, _ = orc.compress_batch(mu[:n], sigma[:n], LAMBDAS)
+    dt = time.perf_counter() - t0
+    ok = None
+    m = min(n, 256)
+    if idx_check is not None and idx_check.shape[1] >= m:
+        q = np.stack([O.qidx_lookup(orc.by_channel, Z[i][:m]).T for i in range(L)])      # [L, m, C]
+        ok = bool(np.array_equal(q.astype(np.uint16), idx_check[:, :m]))
+    return {"value": n * C * L / dt, "unit": "latents/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"first {n} of {rows} rows x {C} channels x {L} lambdas, NumPy restatement of the reference formulation "
+                      f"(oracle/vbq_oracle.py), one process, {dt:.1f} s", "agrees_with_c_oracle": ok}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -270,6 +300,8 @@ def main():
         # the sample doubles as an in-run parity check of the timed configuration
         got = (idx[:, :, :n].permute(0, 2, 1) if C > 1 else idx[:, :n]).cpu().numpy().reshape(idx_cpu.shape)
         out["parity_vs_oracle_on_sample"] = bool(np.array_equal(got, idx_cpu))
+        # the same formulation in NumPy, as the reference runs it (reported next to the C port, never the target)
+        out["cpu_baseline_numpy"] = cpu_baseline_numpy(mu_h, sg_h, tab_h, ll_h, idx_cpu.reshape(L, -1, C) if C > 1 else None)
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:
