@@ -44,6 +44,13 @@ def _worker(rank, world, port, q):
     xs = x[a:b]
     mom = torch.from_numpy(np.stack([xs.sum(0), (xs ** 2).sum(0)], axis=1))
     std = vd.global_empirical_std(mom, xs.shape[0])
+    # the asynchronous int32 reducer bench.py uses (on CPU it reduces the int32 tensor as it is; the packed
+    # 3 x 21-bit form needs the device kernels and is covered by tests/test_gpu_dist.py)
+    c32 = local.to(torch.int32).contiguous()
+    red = vd.CountsAllReduce(c32.numel(), dev, max_global_count=idx.shape[1])
+    assert red.packed is False
+    red.start(c32).wait()
+    assert torch.equal(c32.to(torch.int64), torch.from_numpy(_counts(idx, idx.shape[2])))
     q.put((rank, raw, full, std, (a, b)))
     dist.barrier()
     dist.destroy_process_group()
