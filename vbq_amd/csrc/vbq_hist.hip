@@ -221,7 +221,21 @@ k_moments_flat(const float *__restrict__ x, long n_per_ch, double *__restrict__ 
     const float *src = x + (long)c * n_per_ch;
     double s1 = 0.0, s2 = 0.0;
     const long nq = vec_ok ? (n_per_ch >> 2) : 0;
-    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (long)gridDim.x * blockDim.x) {
+    // four 16-byte loads in flight per lane (one is not enough to cover the HBM latency at 8 waves per SIMD)
+    const long stride = (long)gridDim.x * blockDim.x;
+    long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; q + 3 * stride < nq; q += 4 * stride) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4 *>(src + (q + u * stride) * 4);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const double a = v[u].x, b = v[u].y, cc = v[u].z, d = v[u].w;
+            s1 += (a + b) + (cc + d);
+            s2 += (a * a + b * b) + (cc * cc + d * d);
+        }
+    }
+    for (; q < nq; q += stride) {
         const float4 v = *reinterpret_cast<const float4 *>(src + q * 4);
         const double a = v.x, b = v.y, cc = v.z, d = v.w;
         s1 += (a + b) + (cc + d);
