@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Randomized API fuzz of vbq_quantize_f32 / vbq_histogram_u16 against the C oracle: random shapes, layouts,
+bit depths, lambda counts (above the 32-lambda chunk too), raw / corrected lengths, optional outputs, lambdas
+outside the fast kernel's range, both arithmetic modes.   python tools/fuzz_api.py [--cases 300] [--seed 0]"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from scipy.stats import norm
+
+from oracle import c_oracle as CO
+from vbq_amd import ops
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--cases", type=int, default=300)
+ap.add_argument("--seed", type=int, default=0)
+a = ap.parse_args()
+rng = np.random.default_rng(a.seed)
+dev = torch.device("cuda")
+bad = 0
+solves = 0
+for case in range(a.cases):
+    N = int(rng.integers(4, 11))
+    T = 2 ** (N + 1) - 1
+    C = int(rng.choice([1, 1, 2, 3, 5, 16, 17, 40]))
+    rows = int(rng.choice([1, 2, 7, 64, 511, 512, 513, 1000, 3001]))
+    L = int(rng.choice([1, 2, 5, 32, 33, 40]))
+    layout = "bc" if C == 1 else str(rng.choice(["bc", "cb"]))
+    mode = "f64" if rng.random() < 0.15 else "f32"
+    xi = np.concatenate([(np.arange(2 ** n) + 0.5) / 2 ** n for n in range(N + 1)])
+    scale = np.exp(rng.uniform(np.log(0.1), np.log(10), C))
+    tab = norm.ppf(xi[None, :], scale=scale[:, None]).astype(np.float32)
+    mu = (scale * rng.standard_t(4, (rows, C))).astype(np.float32)
+    sg = (np.exp(rng.normal(-2, 1.2, (rows, C))) * scale).astype(np.float32)
+    if rows > 4:
+        srt = np.sort(tab[0])
+        mu[0, 0] = srt[rng.integers(0, T)]
+        mu[1, 0] = np.float32(0.5 * (float(srt[3]) + float(srt[4])))
+    lam = np.exp(rng.uniform(np.log(1e-3), np.log(300), L))
+    if rng.random() < 0.2:
+        lam[rng.integers(0, L)] = float(rng.choice([0.0, 1e-14, 1e20]))        # outside the fast kernel's range
+    ll = None
+    if mode == "f32" and rng.random() < 0.6:
+        ll = (np.arange(N + 1, dtype=np.float32)[None, None, :] + np.abs(rng.normal(0, 1.5, (L, C, N + 1)))).astype(np.float32)
+    wz, wb = bool(rng.random() < 0.4), bool(rng.random() < 0.4)
+    want = CO.quantize(mu, sg, tab, list(lam), N=N, level_len=ll, mode=1 if mode == "f64" else 0, want_zhat=wz,
+                       want_bits=wb, threads=8)
+    want = want if isinstance(want, tuple) else (want,)
+    m_in, s_in = (mu[:, 0], sg[:, 0]) if C == 1 else ((mu, sg) if layout == "bc" else (np.ascontiguousarray(mu.T), np.ascontiguousarray(sg.T)))
+    got = ops.quantize(torch.from_numpy(m_in).to(dev), torch.from_numpy(s_in).to(dev), torch.from_numpy(tab).to(dev), list(lam), N=N,
+                       level_len=None if ll is None else torch.from_numpy(ll).to(dev), layout=layout, mode=mode, want_zhat=wz,
+                       want_bits=wb)
+    got = got if isinstance(got, tuple) else (got,)
+
+    def canon(t):
+        x = t.cpu().numpy()
+        if C == 1:
+            return x.reshape(L, rows, 1)
+        return x if layout == "bc" else x.transpose(0, 2, 1)
+    miss = sum(int((canon(g) != w).sum()) for g, w in zip(got, want))
+    hist = ops.histogram(got[0], C, N=N, layout=layout).cpu().numpy()
+    hw = CO.histogram(want[0], C, N=N)
+    miss += int((hist != hw).sum())
+    solves += rows * C * L
+    if miss:
+        bad += 1
+        print(f"case {case}: N={N} C={C} rows={rows} L={L} layout={layout} mode={mode} ll={ll is not None} zhat={wz} bits={wb}: {miss} mismatches")
+print(f"{a.cases} cases, {solves:.3g} solves, {bad} failing cases")
+sys.exit(1 if bad else 0)
