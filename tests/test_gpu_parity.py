@@ -323,3 +323,10 @@ def test_notebook_and_histogram_other_bit_depths(ops, Nbits):
     want = CO.histogram(host(idx)[:, :, None], 1, N=Nbits)
     got = host(ops.histogram(idx, 1, N=Nbits))
     assert got.shape == (3, 1, Tn) and np.array_equal(got, want)
+
+
+def test_api_fuzz_small(ops):
+    """A short run of tools/fuzz_api.py: random shapes / layouts / bit depths / lambda counts / lengths / outputs."""
+    from tools import fuzz_api
+    bad, solves = fuzz_api.run(60, seed=123, verbose=True)
+    assert bad == 0 and solves > 1e6

@@ -15,15 +15,25 @@ from scipy.stats import norm
 from oracle import c_oracle as CO
 from vbq_amd import ops
 
-ap = argparse.ArgumentParser()
-ap.add_argument("--cases", type=int, default=300)
-ap.add_argument("--seed", type=int, default=0)
-a = ap.parse_args()
-rng = np.random.default_rng(a.seed)
-dev = torch.device("cuda")
-bad = 0
-solves = 0
-for case in range(a.cases):
+
+
+def run(cases, seed, verbose=True):
+    """Returns (failing cases, solves compared)."""
+    rng = np.random.default_rng(seed)
+    dev = torch.device("cuda")
+    bad = 0
+    solves = 0
+    for case in range(cases):
+        bad_case, n = one_case(rng, dev)
+        solves += n
+        if bad_case:
+            bad += 1
+            if verbose:
+                print(f"case {case}: {bad_case}")
+    return bad, solves
+
+
+def one_case(rng, dev):
     N = int(rng.integers(4, 11))
     T = 2 ** (N + 1) - 1
     C = int(rng.choice([1, 1, 2, 3, 5, 16, 17, 40]))
@@ -65,9 +75,15 @@ for case in range(a.cases):
     hist = ops.histogram(got[0], C, N=N, layout=layout).cpu().numpy()
     hw = CO.histogram(want[0], C, N=N)
     miss += int((hist != hw).sum())
-    solves += rows * C * L
-    if miss:
-        bad += 1
-        print(f"case {case}: N={N} C={C} rows={rows} L={L} layout={layout} mode={mode} ll={ll is not None} zhat={wz} bits={wb}: {miss} mismatches")
-print(f"{a.cases} cases, {solves:.3g} solves, {bad} failing cases")
-sys.exit(1 if bad else 0)
+    desc = f"N={N} C={C} rows={rows} L={L} layout={layout} mode={mode} ll={ll is not None} zhat={wz} bits={wb}: {miss} mismatches"
+    return (desc if miss else None), rows * C * L
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=300)
+    ap.add_argument("--seed", type=int, default=0)
+    a = ap.parse_args()
+    bad, solves = run(a.cases, a.seed)
+    print(f"{a.cases} cases, {solves:.3g} solves, {bad} failing cases")
+    sys.exit(1 if bad else 0)
