@@ -68,8 +68,21 @@ k_rans_decode(const uint16_t *__restrict__ words, const uint32_t *__restrict__ s
               const uint16_t *__restrict__ freq, uint16_t *__restrict__ idx) {
     __shared__ uint16_t f_l[2048];
     __shared__ uint32_t c_l[2049];
+    // start[b] = the symbol whose slot range contains slot 16 b: the search for a slot begins there and walks
+    // up (a bucket of 16 slots holds 1 symbol on average), instead of 11 dependent LDS reads of a bisection
+    __shared__ uint16_t start[(1 << kPB) / 16];
     const long s = blockIdx.y;
     stage_tables(freq + s * T, T, f_l, c_l);
+    for (int bkt = threadIdx.x; bkt < (1 << kPB) / 16; bkt += kRansThreads) {
+        const unsigned slot = 16u * bkt;
+        int lo = 0, hi = T;                                      // last symbol with cum <= slot
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (c_l[mid] <= slot) lo = mid; else hi = mid;
+        }
+        start[bkt] = (uint16_t)lo;
+    }
+    __syncthreads();
     const int g = blockIdx.x * kRansThreads + threadIdx.x;
     if (g >= nseg) return;
     const long a = (long)g * seg;
@@ -81,11 +94,8 @@ k_rans_decode(const uint16_t *__restrict__ words, const uint32_t *__restrict__ s
     uint16_t *dst = idx + s * n;
     for (long i = a; i < b; ++i) {
         const unsigned slot = x & ((1u << kPB) - 1u);
-        int lo = 0, hi = T;                                      // last symbol with cum <= slot
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (c_l[mid] <= slot) lo = mid; else hi = mid;
-        }
+        int lo = start[slot >> 4];                               // last symbol with cum <= slot
+        while (c_l[lo + 1] <= slot) ++lo;                        // c_l[T] = 2^15 > slot ends the walk
         dst[i] = (uint16_t)lo;
         x = f_l[lo] * (x >> kPB) + slot - c_l[lo];
         if (x < kRansL) x = (x << 16) | in[--k];
