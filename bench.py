@@ -244,7 +244,7 @@ def main():
 
     # HBM traffic of K1 per launch from the committed PMC passes (profiles/*_pmc.json): 2 x FETCH_SIZE +
     # WRITE_SIZE, collected with rocprofv3 --pmc in separate runs of this same workload.
-    traffic, traffic_src = None, None
+    traffic, traffic_src, valu_note = None, None, None
     try:
         import glob
         for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), reverse=True):
@@ -254,6 +254,11 @@ def main():
                     bl.get("workload", "").startswith(args.workload + ":") and \
                     "hbm_bytes_per_launch" in pj["k_quant_fast"]:
                 traffic, traffic_src = pj["k_quant_fast"]["hbm_bytes_per_launch"], os.path.relpath(f, ROOT)
+                sqc = pj["k_quant_fast"].get("sq", {})
+                if "SQ_INSTS_VALU" in sqc:          # why the HBM fraction is what it is: the kernel is VALU-issue-bound
+                    valu_note = {"valu_wave_instructions_per_launch": sqc["SQ_INSTS_VALU"],
+                                 "valu_instructions_per_latent": sqc["SQ_INSTS_VALU"] * 64.0 / (rows * C * L),
+                                 "clock_GHz_under_load": sqc.get("clock_GHz"), "source": traffic_src}
                 break
     except Exception:
         pass
@@ -286,7 +291,7 @@ def main():
                          "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": k1_ms,
-                         "latents_per_s_kernel_only": E * L / (k1_ms * 1e-3)},
+                         "latents_per_s_kernel_only": E * L / (k1_ms * 1e-3), "valu": valu_note},
             "stages_ms": {"k1_solve": k1_ms, "k2_histogram": k2_ms},
             "roofline_k2_histogram": (None if k2_ms is None else
                                       {"bound": "hbm", "kernel": "k_hist_flat", "achieved": 2.0 * L * E / (k2_ms * 1e-3) / 1e9,
