@@ -1,18 +1,19 @@
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, '/root/repo')
 import numpy as np, torch
 from bench import LAMBDAS, make_inputs, N_BITS
 from vbq_amd import ops
 from tools.kbench import timeit
 dev = torch.device("cuda")
-n = 10_000_000
-mu, sg, tab = make_inputs(n, 1, 0)
-mu, sg, tab = (torch.from_numpy(a).to(dev) for a in (mu.ravel(), sg.ravel(), tab))
-idx = ops.quantize(mu, sg, tab, LAMBDAS, N=N_BITS)
-for l in range(0, 32, 3):
-    one = idx[l:l + 1].contiguous()
-    cnt = torch.zeros((1, 1, 2047), dtype=torch.int64, device=dev)
-    med, best = timeit(lambda: ops.histogram(one, 1, N=N_BITS, out=cnt), 10)
-    c = ops.histogram(one, 1, N=N_BITS)[0, 0].cpu().numpy()
-    top = np.sort(c)[::-1]
-    print(f"lambda[{l}]={LAMBDAS[l]:.4g}: {med*1e3:.1f} us  distinct bins={np.count_nonzero(c)}  top1={top[0]/n:.3f} top4={top[:4].sum()/n:.3f}")
+rows, C = 36864, 256
+mu, sg, tab = make_inputs(rows, C, 0)
+mu_t, sg_t = (torch.from_numpy(np.ascontiguousarray(a.T)).to(dev) for a in (mu, sg))
+tab = torch.from_numpy(tab).to(dev)
+idx = ops.quantize(mu_t, sg_t, tab, LAMBDAS, N=N_BITS, layout="cb")
+cnt = torch.zeros((32, C, 2047), dtype=torch.int32, device=dev)
+for l in (0, 4, 8, 12, 16, 20, 24, 28, 31):
+    rep = idx[l:l+1].expand(32, C, rows).contiguous()
+    med, best = timeit(lambda: ops.histogram(rep, C, N=N_BITS, layout="cb", out=cnt), 10)
+    print(f"lambda[{l}]={LAMBDAS[l]:.3g}: K2 on 32 copies {med*1e3:.0f} us")
+med, best = timeit(lambda: ops.histogram(idx, C, N=N_BITS, layout="cb", out=cnt), 10)
+print(f"real sweep: {med*1e3:.0f} us")
