@@ -120,6 +120,8 @@ def main():
     ap.add_argument("--stage", default="full", choices=["full", "quantize"])
     ap.add_argument("--raw-lengths", action="store_true", help="pass-1 lengths (n) instead of corrected lengths")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the step from a captured HIP graph (one GPU; per-kernel times come from an eager pass)")
     args = ap.parse_args()
 
     import torch
@@ -225,12 +227,33 @@ def main():
         step(None, w & 1)
     drain()
     torch.cuda.synchronize()
+    graph = None
+    if args.graph:
+        if world > 1:
+            raise SystemExit("--graph is a single-GPU option")
+        for i in range(args.steps):                   # per-kernel times (HIP events cannot sit inside the graph)
+            step(i, 0)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        cs = torch.cuda.Stream()
+        cs.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(cs):
+            step(None, 0)
+        torch.cuda.current_stream().wait_stream(cs)
+        with torch.cuda.graph(graph):
+            step(None, 0)
+        for _ in range(3):
+            graph.replay()
+        torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(i, i & 1)
+        if graph is not None:
+            graph.replay()
+        else:
+            step(i, i & 1)
     drain()
     torch.cuda.synchronize()
     if world > 1:
@@ -286,7 +309,8 @@ def main():
                                    f"N={N_BITS} (2047 code points/channel); "
                                    f"{'raw' if args.raw_lengths else 'corrected'} code lengths; stage={args.stage} "
                                    f"({'layout change + ' if C > 1 else ''}K1 solve{' + K2 histogram' + (' + RCCL all-reduce' if world > 1 else '') if args.stage == 'full' else ''})",
-                       "elements_per_gpu": E, "lambdas": L, "parallelism": f"element-sharded x{world}"},
+                       "elements_per_gpu": E, "lambdas": L, "parallelism": f"element-sharded x{world}",
+                       "launch": "hip graph replay" if args.graph else "eager launches"},
             "roofline": {"bound": "hbm", "kernel": "k_quant_fast",
                          "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_src,

@@ -332,3 +332,51 @@ def test_model_table_cache_follows_replaced_models(golden):
     q.entropy_models = {l: np.zeros((C, T), np.float32) for l in lambs}
     d = q.compress_latents(means, logvars, lambs)
     assert all(not d["num_bits"][l].any() for l in lambs)
+
+
+def test_entry_points_are_graph_capturable():
+    """The C-ABI launches only stream-ordered work on the caller's stream (no allocation, no synchronisation), so a
+    whole entropy-model pass -- layout change, K1, K2 -- can be captured into a HIP graph and replayed."""
+    from vbq_amd import ops
+    rng = np.random.default_rng(31)
+    rows, C, L = 640, 8, 5
+    lambs = [0.05, 0.3, 1.0, 7.0, 60.0]
+    from scipy.stats import norm
+    xi = np.concatenate([(np.arange(2 ** n) + 0.5) / 2 ** n for n in range(N + 1)])
+    tab = torch.from_numpy(norm.ppf(xi[None, :], scale=np.linspace(0.5, 2.0, C)[:, None]).astype(np.float32)).cuda()
+    mu_in = torch.from_numpy(rng.normal(0, 1, (rows, C)).astype(np.float32)).cuda()
+    sg_in = torch.from_numpy(np.exp(rng.normal(-2, 0.6, (rows, C))).astype(np.float32)).cuda()
+    mu, sg = torch.empty((C, rows), device="cuda"), torch.empty((C, rows), device="cuda")
+    idx = torch.empty((L, C, rows), dtype=torch.uint16, device="cuda")
+    cnt = torch.zeros((L, C, T), dtype=torch.int32, device="cuda")
+    ws = torch.empty(ops._lib.lib().vbq_quantize_workspace_bytes(C, L, N), dtype=torch.uint8, device="cuda")
+
+    def step():
+        ops.transpose(mu_in, out=mu)
+        ops.transpose(sg_in, out=sg)
+        ops.quantize(mu, sg, tab, lambs, N=N, layout="cb", out_idx=idx, workspace=ws)
+        cnt.zero_()
+        ops.histogram(idx, C, N=N, layout="cb", out=cnt)
+
+    step()
+    torch.cuda.synchronize()
+    want_idx, want_cnt = idx.clone(), cnt.clone()
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        step()                                           # warm-up on the capture stream
+    torch.cuda.current_stream().wait_stream(s)
+    with torch.cuda.graph(g):
+        step()
+    # new inputs, replay: the graph must recompute from the (updated) input buffers
+    mu_in.copy_(torch.from_numpy(rng.normal(0, 1, (rows, C)).astype(np.float32)).cuda())
+    idx.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    step_idx, step_cnt = idx.clone(), cnt.clone()
+    step()
+    torch.cuda.synchronize()
+    assert torch.equal(step_idx.view(torch.int16), idx.view(torch.int16)) and torch.equal(step_cnt, cnt)
+    assert not torch.equal(step_idx.view(torch.int16), want_idx.view(torch.int16))
+    assert int(cnt.sum()) == L * C * rows
