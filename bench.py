@@ -120,6 +120,9 @@ def main():
     ap.add_argument("--stage", default="full", choices=["full", "quantize"])
     ap.add_argument("--raw-lengths", action="store_true", help="pass-1 lengths (n) instead of corrected lengths")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--notebook", action="store_true",
+                    help="C = 1 workloads in the word-embedding notebook's arithmetic (K1n: f64 squared error, penalty "
+                         "fl32(2 beta sigma^2) * length, ipynb:429-443) instead of the image pipeline's f32 score")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step from a captured HIP graph (one GPU; per-kernel times come from an eager pass)")
     args = ap.parse_args()
@@ -152,6 +155,9 @@ def main():
 
     rows, C, desc = WORKLOADS[args.workload]
     L = len(LAMBDAS)
+    if args.notebook and C != 1:
+        raise SystemExit("--notebook applies to the one-code-book (C = 1) workloads")
+    BETAS = [float(b) for b in np.exp(np.linspace(np.log(0.01), np.log(1e5), L))]      # ipynb cell 32's range, L points
     mu_h, sg_h, tab_h = make_inputs(rows, C, seed=1000 + rank)
     mu, sg, tab = torch.from_numpy(mu_h).to(dev), torch.from_numpy(sg_h).to(dev), torch.from_numpy(tab_h).to(dev)
     E = rows * C
@@ -179,9 +185,14 @@ def main():
         reducers = [CountsAllReduce(L * C * T, dev, max_global_count=rows * world) if cdtype == torch.int32 else None for _ in range(2)]
     ws = torch.empty(ops._lib.lib().vbq_quantize_workspace_bytes(C, L, N_BITS), dtype=torch.uint8, device=dev)
 
+    codebook = None
+    if args.notebook:
+        from vbq_amd import embeddings as Emb
+        pts_h, lens_h = Emb.make_code_book(Emb.empirical_std(mu), N_BITS)              # ipynb:373-390
+        codebook = torch.from_numpy(pts_h).to(dev)
     # setup (untimed): pass 1 with raw lengths -> bit-length histogram -> corrected lengths (quantizer.py:96-112)
     level_len = None
-    if not args.raw_lengths:
+    if not args.raw_lengths and not args.notebook:
         from vbq_amd.entropy import level_lengths_from_counts
         ops.quantize(mu, sg, tab, LAMBDAS, N=N_BITS, layout=layout, out_idx=idx, workspace=ws)
         c1 = ops.histogram(idx, C, N=N_BITS, layout=layout)
@@ -202,7 +213,10 @@ def main():
             ops.transpose(sg_in, out=sg)
         if i is not None:
             ev[i][0].record()
-        ops.quantize(mu, sg, tab, LAMBDAS, N=N_BITS, level_len=level_len, layout=layout, out_idx=idx, workspace=ws)
+        if args.notebook:
+            ops.quantize_notebook(mu, sg, codebook, BETAS, N=N_BITS, want_values=False, out_idx=idx)
+        else:
+            ops.quantize(mu, sg, tab, LAMBDAS, N=N_BITS, level_len=level_len, layout=layout, out_idx=idx, workspace=ws)
         if i is not None:
             ev[i][1].record()
         if args.stage == "full":
@@ -305,13 +319,16 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {desc}; {L}-point lambda sweep 2**linspace(-8,7.5,32); "
-                                   f"N={N_BITS} (2047 code points/channel); "
-                                   f"{'raw' if args.raw_lengths else 'corrected'} code lengths; stage={args.stage} "
+            "config": {"workload": f"{args.workload}: {desc}; "
+                                   + (f"{L}-point beta sweep exp(linspace(log 0.01, log 1e5, {L})), notebook arithmetic (K1n, f64 "
+                                      f"squared error, ipynb:429-443); " if args.notebook else
+                                      f"{L}-point lambda sweep 2**linspace(-8,7.5,32); ")
+                                   + f"N={N_BITS} (2047 code points/channel); "
+                                   f"{'raw' if args.raw_lengths or args.notebook else 'corrected'} code lengths; stage={args.stage} "
                                    f"({'layout change + ' if C > 1 else ''}K1 solve{' + K2 histogram' + (' + RCCL all-reduce' if world > 1 else '') if args.stage == 'full' else ''})",
                        "elements_per_gpu": E, "lambdas": L, "parallelism": f"element-sharded x{world}",
                        "launch": "hip graph replay" if args.graph else "eager launches"},
-            "roofline": {"bound": "hbm", "kernel": "k_quant_fast",
+            "roofline": {"bound": "hbm", "kernel": "k_quant_notebook_fast" if args.notebook else "k_quant_fast",
                          "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": k1_ms,
@@ -322,7 +339,21 @@ def main():
                                        "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": 2.0 * L * E / (k2_ms * 1e-3) / HBM_PEAK,
                                        "algorithmic_bytes_per_launch": 2 * L * E, "avg_launch_ms": k2_ms}),
         }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.notebook:
+        # the notebook's own brute force over all 2047 code points (C oracle, OpenMP), a bounded sample
+        from oracle import c_oracle as CO, vbq_oracle as O
+        th = CO.max_threads()
+        n = int(min(rows, 400_000))
+        r2s = O.level_major_to_rank(N_BITS)
+        t0 = time.perf_counter()
+        slots = [CO.compress_coordinates(mu_h[:n, 0], sg_h[:n, 0], b, pts_h, lens_h, threads=th)[1] for b in BETAS]
+        dtc = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": n * L / dtc, "unit": "latents/s", "cores": th, "kind": "port",
+                               "sample": f"first {n} of {rows} elements x {L} betas, C oracle of compress_coordinates "
+                                         f"(2047-point f64 brute force, OpenMP {th} threads), {dtc:.1f} s"}
+        got = idx[:, :n].cpu().numpy().astype(np.int64)
+        out["parity_vs_oracle_on_sample"] = bool(all(np.array_equal(got[i], r2s[slots[i]]) for i in range(L)))
+    elif rank == 0 and world == 1 and not args.no_cpu_baseline:
         ll_h = level_len.cpu().numpy() if level_len is not None else None
         cb, idx_cpu, n = cpu_baseline(mu_h, sg_h, tab_h, ll_h)
         out["cpu_baseline"] = cb

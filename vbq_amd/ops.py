@@ -111,7 +111,7 @@ def quantize(mu: torch.Tensor, sigma: torch.Tensor, table_lm: torch.Tensor, lamb
 
 
 def quantize_notebook(means: torch.Tensor, stds: torch.Tensor, codebook_lm: torch.Tensor, betas: Sequence[float], *,
-                      N: int = 10, want_values: bool = True):
+                      N: int = 10, want_values: bool = True, out_idx: Optional[torch.Tensor] = None):
     """K1n (vbq_quantize_notebook_f64).  Returns (idx u16 [n_beta, *shape], values f32 or None)."""
     means = _dev(means, torch.float32, "means")
     stds = _dev(stds, torch.float32, "stds")
@@ -122,7 +122,12 @@ def quantize_notebook(means: torch.Tensor, stds: torch.Tensor, codebook_lm: torc
         raise ValueError(f"codebook has {codebook_lm.numel()} entries, expected {table_size(N)}")
     nb = len(betas)
     n = means.numel()
-    idx = torch.empty((nb,) + tuple(means.shape), dtype=torch.uint16, device=means.device)
+    if out_idx is not None:
+        if tuple(out_idx.shape) != (nb,) + tuple(means.shape) or out_idx.dtype != torch.uint16 or not out_idx.is_contiguous():
+            raise ValueError(f"out_idx: expected a contiguous uint16 tensor of shape {(nb,) + tuple(means.shape)}")
+        idx = out_idx
+    else:
+        idx = torch.empty((nb,) + tuple(means.shape), dtype=torch.uint16, device=means.device)
     val = torch.empty((nb,) + tuple(means.shape), dtype=torch.float32, device=means.device) if want_values else None
     check(_lib.lib().vbq_quantize_notebook_f64(_ptr(means), _ptr(stds), n, _ptr(codebook_lm), _doubles(betas), nb, N,
                                                _ptr(idx), _ptr(val), _stream(means)), "vbq_quantize_notebook_f64")
