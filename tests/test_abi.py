@@ -65,3 +65,25 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.delenv("VBQ_HIP_LIBRARY")
     monkeypatch.setattr(_lib, "_LIB", None)
     assert _lib.lib() is not None
+
+
+def test_argument_validation_of_the_newer_entry_points(built_lib):
+    """Every entry point validates sizes and pointers before touching the device: callable on a CPU-only host."""
+    import ctypes as C
+    from vbq_amd import _lib
+    h = _lib.lib()
+    assert h.vbq_analogy_ranks_workspace_bytes(100_000, 100, 19_544) > 4 * 100_000 * 100
+    assert h.vbq_analogy_ranks_workspace_bytes(0, 100, 10) == 0
+    assert h.vbq_analogy_ranks_f32(None, 0, 100, None, 5, None, None, 0, None) == -1 and b"bad shape" in h.vbq_last_error()
+    assert h.vbq_analogy_ranks_f32(None, 10, 4, None, 5, None, None, 0, None) == -1 and b"null pointer" in h.vbq_last_error()
+    assert h.vbq_analogy_ranks_f32(None, 10, 4, None, 0, None, None, 0, None) == 0            # no questions: nothing to do
+    assert h.vbq_uniform_quantize_f32(None, 5, C.c_float(0), C.c_float(0), C.c_float(0), 4, None, None, None, None) == -1
+    assert h.vbq_nearest_code_f64(None, 5, None, 0, None, None, None, None) == -1
+    assert h.vbq_ssim_scale_workspace_bytes(2, 64, 64, 3, 11) == 2 * 8 * 2 * 3 * 4 * 4
+    assert h.vbq_ssim_scale_workspace_bytes(2, 8, 64, 3, 11) == 0                              # window larger than the image
+    assert h.vbq_ssim_scale_f64(None, None, 1, 8, 8, 1, None, 12, C.c_double(1), C.c_double(1), None, None, None, 0, None) == -1
+    assert b"window" in h.vbq_last_error()
+    assert h.vbq_image_sqerr_u8(None, None, -1, 4, None, None) == -1
+    assert h.vbq_pack_counts_3x21(None, -1, None, None) == -1 and h.vbq_pack_counts_3x21(None, 0, None, None) == 0
+    assert h.vbq_downsample2_f64(None, 1, 0, 4, 1, None, None) == -1
+    assert h.vbq_transpose_f32(None, 4, 4, None, None) == -1
