@@ -30,7 +30,9 @@ Pinning status (see tests/golden/README.md and DESIGN.md):
   interval functions, ``encode_vectorized``, ``batch_quantize_indep_dims`` (NumPy
   backend, both the f32 op-by-op mode that reproduces the TF path's rounding and
   the as-written f64 mode), ``quantize_indep_dims`` brute force, and the notebook
-  cells ``compress_coordinates`` / ``empirical_entropy`` / code book / moment.
+  cells ``compress_coordinates`` / ``empirical_entropy`` / code book / moment; and, for the rows around the
+  path: the comparison quantizers (G9), ``prediction_ranks`` / ``quantize_coordinates`` (G10,
+  up to f32 near-ties of the BLAS product) and the image metrics (G11; ms_ssim to 1e-9, fftconvolve).
 * RESTATED, cross-checked but not directly executable here (TensorFlow is not in
   the image, quantizer.py / learned_prior.py import it at module top): the
   interval search on padded grids, the candidate assembly and the two-pass entropy
