@@ -28,6 +28,8 @@ import time
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
+# the host driver only supports dmabuf IPC: RCCL between processes needs this before HIP initialises
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 sys.path.insert(0, ROOT)
 
 N_BITS = 10

@@ -19,6 +19,7 @@ import torch.distributed as dist
 def init_from_env(backend: Optional[str] = None):
     """Initialise torch.distributed from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*; returns
     (rank, world, device).  backend "nccl" is RCCL on ROCm; "gloo" is used on CPU-only hosts."""
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this driver (RCCL across processes)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
