@@ -46,7 +46,7 @@ Pinning status (see tests/golden/README.md and DESIGN.md):
 from __future__ import annotations
 
 import collections
-from typing import Callable, Dict, Iterable, Sequence, Tuple
+from typing import Callable, Dict, Sequence
 
 import numpy as np
 

@@ -1,7 +1,6 @@
 """The NumPy oracle against the golden vectors captured from the reference
 (tests/golden/make_golden.py).  CPU only."""
 import numpy as np
-import pytest
 from scipy.stats import norm
 
 from oracle import vbq_oracle as O

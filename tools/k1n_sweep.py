@@ -1,4 +1,4 @@
-import os, sys
+import sys
 sys.path.insert(0, '/root/repo')
 import numpy as np, torch
 from vbq_amd import embeddings as E, ops

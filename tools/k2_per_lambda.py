@@ -1,4 +1,4 @@
-import os, sys
+import sys
 sys.path.insert(0, '/root/repo')
 import numpy as np, torch
 from bench import LAMBDAS, make_inputs, N_BITS

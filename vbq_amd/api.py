@@ -1,7 +1,7 @@
 """quantize(mu, sigma, lmbda): the one-call surface named by BASELINE.json's north_star."""
 from __future__ import annotations
 
-from typing import Optional, Sequence, Union
+from typing import Sequence, Union
 
 import numpy as np
 import torch

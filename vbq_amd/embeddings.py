@@ -10,14 +10,13 @@
 """
 from __future__ import annotations
 
-from typing import Optional, Sequence
+from typing import Sequence
 
 import numpy as np
 import torch
 
 from . import ops
 from ._lib import VBQError
-from .tables import rank_of_slot
 
 
 def _device():

@@ -6,7 +6,6 @@ from __future__ import annotations
 import ctypes as C
 from typing import Optional, Sequence
 
-import numpy as np
 import torch
 
 from . import _lib

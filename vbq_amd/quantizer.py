@@ -17,7 +17,7 @@ There is no CPU path: without the HIP extension and a ROCm device the methods ra
 """
 from __future__ import annotations
 
-from typing import Dict, Optional, Sequence
+from typing import Dict, Optional
 
 import numpy as np
 import torch
