@@ -135,6 +135,9 @@ with open(os.path.join(dst, f"{tag}_summary.md"), "w") as f:
                 f"{c.get('lds_busy_frac', 0):.2f} | {c.get('SQ_LDS_BANK_CONFLICT', 0):.3g} |\n")
     f.write("\nVALU-active / SIMD time can exceed 1: SQ_ACTIVE_INST_VALU counts a quad-cycle per issued VALU instruction, "
             "while add/sub/mul/logic ops issue in 2 cycles per wave64 on gfx950 (tools/ubench.hip).\n")
+    isa = os.path.join(dst, f"{tag}_k1_lambda_loop_isa.txt")
+    if os.path.exists(isa):
+        f.write(f"\nK1 instruction listing of the per-lambda loop: profiles/{os.path.basename(isa)}.\n")
     if "bench_line" in out:
         f.write("\nBench line of the same build (un-profiled run):\n\n```json\n" + json.dumps(out["bench_line"]) + "\n```\n")
 print(open(os.path.join(dst, f"{tag}_summary.md")).read())
