@@ -143,3 +143,47 @@ def test_counts_all_reduce_packed_equals_plain():
         assert res[r][0][0] is True and res[r][1][0] is False
         for i in range(2):
             assert np.array_equal(res[r][i][1], want[i])
+
+
+def _rccl_single_rank_worker(port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as dist
+    from vbq_amd.dist import CountsAllReduce
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    rng = np.random.default_rng(7)
+    c = torch.from_numpy(rng.integers(0, 30000, (4, 3, 2047)).astype(np.int32)).to(dev)
+    want = c.clone()
+    ok = []
+    for limit in (36864, 1 << 30):                                  # packed int64 words, then plain int32
+        red = CountsAllReduce(c.numel(), dev, max_global_count=limit)
+        red.start(c).wait()
+        torch.cuda.synchronize()
+        ok.append(bool(torch.equal(c, want)))
+    t = torch.ones(5, dtype=torch.float64, device=dev)
+    dist.all_reduce(t)
+    ok.append(bool(torch.equal(t.cpu(), torch.ones(5, dtype=torch.float64))))
+    dist.barrier()
+    dist.destroy_process_group()
+    out.put(ok)
+
+
+@pytest.mark.timeout(300)
+def test_rccl_backend_single_rank():
+    """The collectives of the N > 1 path on the real backend (RCCL, one rank: the box has one GPU): process-group
+    creation with device_id, int64 / int32 SUM all-reduce through CountsAllReduce, f64 all-reduce, barrier."""
+    if not torch.cuda.is_available():
+        pytest.fail("gpu-marked test run without a ROCm device")
+    import torch.distributed as dist
+    if not dist.is_nccl_available():
+        pytest.skip("torch.distributed was built without the nccl (RCCL) backend")
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    p = ctx.Process(target=_rccl_single_rank_worker, args=(29950 + os.getpid() % 40, out))
+    p.start()
+    res = out.get(timeout=240)
+    p.join(60)
+    assert p.exitcode == 0 and res == [True, True, True]
