@@ -93,8 +93,10 @@ int vbq_device_name(int dev, char *buf, size_t buflen);
  *   d_out_zhat      optional f32, same shape: the winning code point (Z_hat).
  *   d_out_bits      optional f32, same shape: its code length (num_bits).
  *   d_workspace     vbq_quantize_workspace_bytes() bytes of device scratch.
- *   N               max_bits_per_coord; kernels are built for 4 <= N <= 10 (the reference uses 10,
- *                   post_process.py:117), other values return VBQ_ERR_UNSUPPORTED.
+ *   N               max_bits_per_coord; kernels are built for 4 <= N <= 12 (the reference uses 10,
+ *                   post_process.py:117); N = 11, 12 for channel-major planes / one code book only
+ *                   (16 channel tables no longer fit the LDS); the notebook solve and the coder stop at
+ *                   10.  Other values return VBQ_ERR_UNSUPPORTED.
  * ---------------------------------------------------------------------------------- */
 size_t vbq_quantize_workspace_bytes(int32_t n_ch, int32_t n_lambda, int32_t N);
 

@@ -380,3 +380,33 @@ def test_entry_points_are_graph_capturable():
     assert torch.equal(step_idx.view(torch.int16), idx.view(torch.int16)) and torch.equal(step_cnt, cnt)
     assert not torch.equal(step_idx.view(torch.int16), want_idx.view(torch.int16))
     assert int(cnt.sum()) == L * C * rows
+
+
+def test_quantizer_class_at_eleven_bits():
+    """ChannelwisePriorCDFQuantizer(max_bits_per_coord=11) end to end against the oracle class: tables, two-pass
+    entropy models, compress_latents dict."""
+    from vbq_amd import ChannelwisePriorCDFQuantizer, priors
+    Nb, C = 11, 3
+    rng = np.random.default_rng(77)
+    ch_std = np.array([0.7, 1.0, 2.0])
+    q = ChannelwisePriorCDFQuantizer(C, Nb)
+    q.build_code_points(priors.FactoredGaussianPrior(np.zeros(C), ch_std))
+    orc = O.ChannelwiseOracle(C, Nb)
+    orc.build_code_points(O.factored_gaussian_icdf(np.zeros(C), ch_std))
+    assert np.array_equal(q.all_code_points, orc.all_code_points)
+    mu = (ch_std * rng.normal(0, 1, (900, C))).astype(np.float32)
+    sg = np.exp(rng.normal(-3, 0.8, (900, C))).astype(np.float32)
+    lambs = [0.02, 0.5, 8.0]
+    q.build_entropy_models_from_latents(mu, sg, lambs, add_n_smoothing=1)
+    orc.build_entropy_models(mu, sg, lambs, add_n_smoothing=1)
+    for l in lambs:
+        assert np.array_equal(q.raw_code_length_entropy_models[l], orc.raw_models[l])
+        assert np.array_equal(q.entropy_models[l], orc.entropy_models[l])
+    means = mu[:600].reshape(1, 20, 30, C)
+    logvars = (2 * np.log(sg[:600])).reshape(1, 20, 30, C).astype(np.float32)
+    out = q.compress_latents(means, logvars, lambs)
+    sg2 = np.exp(logvars.reshape(-1, C).astype(np.float32)) ** np.float32(0.5)
+    want = orc.compress_latents(mu[:600], sg2, lambs)
+    for l in lambs:
+        assert np.array_equal(out["Z_hat"][l].reshape(-1, C), want["Z_hat"][l])
+        assert np.array_equal(out["num_bits"][l].reshape(-1, C), want["num_bits"][l])

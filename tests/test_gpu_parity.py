@@ -330,3 +330,34 @@ def test_api_fuzz_small(ops):
     from tools import fuzz_api
     bad, solves = fuzz_api.run(60, seed=123, verbose=True)
     assert bad == 0 and solves > 1e6
+
+
+@pytest.mark.parametrize("Nbits", [11, 12])
+def test_bit_depths_above_ten_on_planes(ops, Nbits):
+    """N = 11, 12 (4095 / 8191 code points): K1 and K2 on channel-major planes and on one code book, raw and
+    corrected lengths, optional outputs; the channel-last form is refused with a pointer to the transpose."""
+    from vbq_amd._lib import VBQError
+    rng = np.random.default_rng(200 + Nbits)
+    C, rows = 3, 1500
+    orc = O.ChannelwiseOracle(C, Nbits)
+    orc.build_code_points(O.factored_gaussian_icdf(np.zeros(C), np.array([1.0, 0.4, 2.5])))
+    mu = rng.normal(0, 1, (rows, C)).astype(np.float32)
+    sg = np.exp(rng.normal(-3, 1.0, (rows, C))).astype(np.float32)
+    mu[:40, 0] = np.sort(orc.all_code_points[0])[rng.integers(0, 2 ** (Nbits + 1) - 1, 40)]      # exact hits
+    lam = LAM32[::3]
+    ll = (np.arange(Nbits + 1, dtype=np.float32)[None, None, :] + np.abs(rng.normal(0, 1, (len(lam), C, Nbits + 1)))).astype(np.float32)
+    for level_len in (None, ll):
+        want_i, want_z, want_b = CO.quantize(mu, sg, orc.all_code_points, lam, N=Nbits, level_len=level_len, want_zhat=True,
+                                             want_bits=True, threads=8)
+        got_i, got_z, got_b = ops.quantize(dev(np.ascontiguousarray(mu.T)), dev(np.ascontiguousarray(sg.T)), dev(orc.all_code_points),
+                                           lam, N=Nbits, level_len=None if level_len is None else dev(level_len), layout="cb",
+                                           want_zhat=True, want_bits=True)
+        assert np.array_equal(host(got_i).transpose(0, 2, 1), want_i)
+        assert np.array_equal(host(got_z).transpose(0, 2, 1), want_z) and np.array_equal(host(got_b).transpose(0, 2, 1), want_b)
+        got1 = ops.quantize(dev(mu[:, 1].copy()), dev(sg[:, 1].copy()), dev(orc.all_code_points[1:2]), lam, N=Nbits,
+                            level_len=None if level_len is None else dev(level_len[:, 1:2].copy()))
+        assert np.array_equal(host(got1), want_i[:, :, 1])
+    cnt = host(ops.histogram(got_i, C, N=Nbits, layout="cb"))
+    assert np.array_equal(cnt, CO.histogram(want_i, C, N=Nbits))
+    with pytest.raises(VBQError, match="planes"):
+        ops.quantize(dev(mu), dev(sg), dev(orc.all_code_points), lam, N=Nbits)

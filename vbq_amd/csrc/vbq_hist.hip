@@ -30,10 +30,14 @@ __device__ __forceinline__ unsigned int bin_slot(unsigned int q) { return q ^ (q
 // equal its first one and issues the other seven adds only where they differ (few active
 // lanes); (2) the lanes whose first index equals the wave leader's are summed with four
 // ballots and added by one lane.  Spread-out distributions pay ~10 extra VALU ops per index.
-constexpr int kHistCopies = 4;            // private copies of the bins per workgroup (lane & 3 picks one); 8 copies measured slower
+// private copies of the bins per workgroup (lane & (K-1) picks one): 4 for up to 2048 bins (8 copies measured
+// slower), 2 / 1 for the 4095 / 8191 bins of N = 11 / 12 -- always 32 KB of LDS
+__host__ __device__ constexpr int hist_slots(int T) { return T + 1 <= 2048 ? 2048 : (T + 1 <= 4096 ? 4096 : 8192); }
+__host__ __device__ constexpr int hist_copies(int T) { return 8192 / hist_slots(T); }
 // The copies of a bin are adjacent words (word = 4 * slot + copy): lanes of different copies never meet on a
 // bank, and zeroing / flushing the 32 KB moves 16 bytes per LDS instruction.
 
+template <int kHistCopies>
 __device__ __forceinline__ void hist_add8(unsigned int *h, const uint4 v) {
     unsigned int s[8];
     {
@@ -74,8 +78,9 @@ __global__ void __launch_bounds__(kHistThreads)
 k_hist_flat(const uint16_t *__restrict__ idx, long n_per_ch, int C, long E,
             CountT *__restrict__ counts, int vec_ok) {
     constexpr int T = table_size(N);
-    static_assert(T + 1 <= 2048, "bin copies are laid out for at most 2048 bins");
-    __shared__ __align__(16) unsigned int h[kHistCopies * 2048];
+    constexpr int kHistCopies = hist_copies(T);
+    static_assert(T + 1 <= 8192, "bins are laid out for at most 8192 slots");
+    __shared__ __align__(16) unsigned int h[8192];
     const int c = blockIdx.y, l = blockIdx.z;
     const uint16_t *src = idx + (long)l * E + (long)c * n_per_ch;
     const long noct = vec_ok ? (n_per_ch >> 3) : 0;
@@ -95,7 +100,7 @@ k_hist_flat(const uint16_t *__restrict__ idx, long n_per_ch, int C, long E,
         for (int u = 0; u < U; ++u) A[u] = *reinterpret_cast<const uint4 *>(src + (q + u * stride) * 8);
         q += U * stride;
     }
-    for (int i = threadIdx.x; i < 2048; i += blockDim.x) reinterpret_cast<uint4 *>(h)[i] = make_uint4(0, 0, 0, 0);
+    for (int i = threadIdx.x; i < 2048; i += blockDim.x) reinterpret_cast<uint4 *>(h)[i] = make_uint4(0, 0, 0, 0);   // 32 KB
     __syncthreads();
     while (haveA) {
         const bool haveB = full(q, U);
@@ -105,7 +110,7 @@ k_hist_flat(const uint16_t *__restrict__ idx, long n_per_ch, int C, long E,
             q += U * stride;
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) hist_add8(h, A[u]);
+        for (int u = 0; u < U; ++u) hist_add8<kHistCopies>(h, A[u]);
         if (!haveB) break;
         haveA = full(q, U);
         if (haveA) {
@@ -114,9 +119,9 @@ k_hist_flat(const uint16_t *__restrict__ idx, long n_per_ch, int C, long E,
             q += U * stride;
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) hist_add8(h, B[u]);
+        for (int u = 0; u < U; ++u) hist_add8<kHistCopies>(h, B[u]);
     }
-    for (; full(q, 1); q += stride) hist_add8(h, *reinterpret_cast<const uint4 *>(src + q * 8));
+    for (; full(q, 1); q += stride) hist_add8<kHistCopies>(h, *reinterpret_cast<const uint4 *>(src + q * 8));
     for (; q < noct; q += stride) {
         const uint4 v = *reinterpret_cast<const uint4 *>(src + q * 8);
         const unsigned int w[4] = {v.x, v.y, v.z, v.w};
@@ -131,8 +136,16 @@ k_hist_flat(const uint16_t *__restrict__ idx, long n_per_ch, int C, long E,
     __syncthreads();
     CountT *dst = counts + ((long)l * C + c) * T;
     for (int i = threadIdx.x; i < T; i += blockDim.x) {
-        const uint4 q4 = reinterpret_cast<const uint4 *>(h)[bin_slot(i)];
-        const unsigned int v = (q4.x + q4.y) + (q4.z + q4.w);
+        unsigned int v;
+        if constexpr (kHistCopies == 4) {
+            const uint4 q4 = reinterpret_cast<const uint4 *>(h)[bin_slot(i)];
+            v = (q4.x + q4.y) + (q4.z + q4.w);
+        } else if constexpr (kHistCopies == 2) {
+            const uint2 q2 = reinterpret_cast<const uint2 *>(h)[bin_slot(i)];
+            v = q2.x + q2.y;
+        } else {
+            v = h[bin_slot(i)];
+        }
         if (v) atomicAdd(&dst[i], (CountT)v);
     }
 }
@@ -182,6 +195,9 @@ int launch_hist(const uint16_t *idx, int64_t n_rows, int32_t n_ch, int32_t layou
         hipLaunchKernelGGL((k_hist_flat<N, CountT>), dim3((unsigned)gx, (unsigned)n_ch, (unsigned)L), dim3(kHistThreads), 0, st,
                            idx, (long)n_per_ch, (int)n_ch, (long)E, counts, vec_ok);
         VBQ_CHECK_LAUNCH("hist_flat");
+    } else if constexpr (N > 10) {
+        set_error("histogram: N=%d is built for channel-major planes only (VBQ_LAYOUT_CB, or n_ch = 1)", N);
+        return VBQ_ERR_UNSUPPORTED;
     } else {
         constexpr int T = table_size(N);
         const size_t lds = sizeof(unsigned int) * kTileChannels * (T + 2);
@@ -390,6 +406,8 @@ int histogram_entry(const char *who, const uint16_t *d_idx, int64_t n_rows, int3
     if (n_rows == 0) return VBQ_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     switch (N) {
+        case 12: return launch_hist<12, CountT>(d_idx, n_rows, n_ch, layout, n_lambda, cnt, st);
+        case 11: return launch_hist<11, CountT>(d_idx, n_rows, n_ch, layout, n_lambda, cnt, st);
         case 10: return launch_hist<10, CountT>(d_idx, n_rows, n_ch, layout, n_lambda, cnt, st);
         case 9: return launch_hist<9, CountT>(d_idx, n_rows, n_ch, layout, n_lambda, cnt, st);
         case 8: return launch_hist<8, CountT>(d_idx, n_rows, n_ch, layout, n_lambda, cnt, st);
@@ -398,7 +416,7 @@ int histogram_entry(const char *who, const uint16_t *d_idx, int64_t n_rows, int3
         case 5: return launch_hist<5, CountT>(d_idx, n_rows, n_ch, layout, n_lambda, cnt, st);
         case 4: return launch_hist<4, CountT>(d_idx, n_rows, n_ch, layout, n_lambda, cnt, st);
         default:
-            set_error("%s: max_bits_per_coord N=%d not built (have 4 ... 10)", who, N);
+            set_error("%s: max_bits_per_coord N=%d not built (have 4 ... 12)", who, N);
             return VBQ_ERR_UNSUPPORTED;
     }
 }

@@ -374,6 +374,10 @@ int launch_quantize(const float *mu, const float *sg, int64_t n_rows, int32_t n_
             hipLaunchKernelGGL((k_quant_flat<N, PenT>), dim3((unsigned)gx, (unsigned)n_ch), dim3(256), 0, st, mu, sg,
                                (long)n_per_ch, (int)n_ch, table, pen, len_c, Lc, oi, oz, ob, (long)E, vec_ok);
             VBQ_CHECK_LAUNCH("quant_flat");
+        } else if constexpr (N > 10) {
+            set_error("vbq_quantize_f32: N=%d is built for channel-major planes only (VBQ_LAYOUT_CB, or n_ch = 1): "
+                      "16 tables of %d points do not fit the LDS; transpose with vbq_transpose_f32 first", N, table_size(N));
+            return VBQ_ERR_UNSUPPORTED;
         } else {
             constexpr int T = table_size(N);
             constexpr int PS = (N1 + 3) & ~3;
@@ -443,6 +447,8 @@ extern "C" int vbq_quantize_f32(const float *d_mu, const float *d_sigma, int64_t
                                                  h_lambdas, n_lambda, d_out_idx, d_out_zhat, d_out_bits,           \
                                                  d_workspace, st);
     switch (N) {
+        VBQ_DISPATCH_N(12)
+        VBQ_DISPATCH_N(11)
         VBQ_DISPATCH_N(10)
         VBQ_DISPATCH_N(9)
         VBQ_DISPATCH_N(8)
@@ -451,7 +457,7 @@ extern "C" int vbq_quantize_f32(const float *d_mu, const float *d_sigma, int64_t
         VBQ_DISPATCH_N(5)
         VBQ_DISPATCH_N(4)
         default:
-            set_error("vbq_quantize_f32: max_bits_per_coord N=%d not built (have 4 ... 10)", N);
+            set_error("vbq_quantize_f32: max_bits_per_coord N=%d not built (have 4 ... 12)", N);
             return VBQ_ERR_UNSUPPORTED;
     }
 #undef VBQ_DISPATCH_N

@@ -293,7 +293,7 @@ k_quant_fast(const float *__restrict__ mu, const float *__restrict__ sg, long n_
                 // (doubling a float adds 2^23 to its bit pattern, more than the 21 low bits can hold).
                 const uint32_t thr = __float_as_uint(__fmul_rn(S[k], 1.9073486328125e-06f));
                 const uint64_t lr_close = __builtin_amdgcn_uicmp(pk[k], thr, 37);
-                rank[k] = pk[k] & 0x7ffu;
+                rank[k] = pk[k] & ((2u << N) - 1u);                // ranks need N + 1 bits, the gap sits above bit 21
                 fm[k] = never_flag ? 0ull : (force_slow ? ~0ull : (multi | lr_close));
             }
             uint64_t any_flag = 0;
@@ -388,6 +388,10 @@ int launch_quant_fast(const float *mu, const float *sg, int64_t n_per_ch, int32_
 
 template int launch_quant_fast<10>(const float *, const float *, int64_t, int32_t, const float *, const float *,
                                    const float *, int32_t, uint16_t *, float *, float *, int64_t, int, hipStream_t);
+template int launch_quant_fast<12>(const float *, const float *, int64_t, int32_t, const float *, const float *,
+                                  const float *, int32_t, uint16_t *, float *, float *, int64_t, int, hipStream_t);
+template int launch_quant_fast<11>(const float *, const float *, int64_t, int32_t, const float *, const float *,
+                                  const float *, int32_t, uint16_t *, float *, float *, int64_t, int, hipStream_t);
 template int launch_quant_fast<8>(const float *, const float *, int64_t, int32_t, const float *, const float *,
                                   const float *, int32_t, uint16_t *, float *, float *, int64_t, int, hipStream_t);
 template int launch_quant_fast<9>(const float *, const float *, int64_t, int32_t, const float *, const float *,
