@@ -34,12 +34,12 @@ def run(cases, seed, verbose=True):
 
 
 def one_case(rng, dev):
-    N = int(rng.integers(4, 11))
+    N = int(rng.integers(4, 13))
     T = 2 ** (N + 1) - 1
     C = int(rng.choice([1, 1, 2, 3, 5, 16, 17, 40]))
     rows = int(rng.choice([1, 2, 7, 64, 511, 512, 513, 1000, 3001]))
     L = int(rng.choice([1, 2, 5, 32, 33, 40]))
-    layout = "bc" if C == 1 else str(rng.choice(["bc", "cb"]))
+    layout = "bc" if C == 1 else ("cb" if N > 10 else str(rng.choice(["bc", "cb"])))      # N > 10: planes only
     mode = "f64" if rng.random() < 0.15 else "f32"
     xi = np.concatenate([(np.arange(2 ** n) + 0.5) / 2 ** n for n in range(N + 1)])
     scale = np.exp(rng.uniform(np.log(0.1), np.log(10), C))
