@@ -177,3 +177,28 @@ def test_beta_sweep_equals_single_betas():
     for i, b in enumerate(betas):
         assert np.array_equal(sweep[i], np.array(E.test_beta(means, stds, b, cp, analogies_id=an), dtype=np.float64))
     assert np.all(np.diff(sweep[:, 3]) < 0)                       # the rate falls as beta grows
+
+
+def test_evaluate_compression_jpg(tmp_path):
+    """utils.evaluate_compression_jpg: PIL encodes, the GPU scores; keys and values against the oracle."""
+    _need_gpu()
+    from io import BytesIO
+
+    from PIL import Image
+    from oracle import vbq_oracle as o
+    from vbq_amd import utils
+    yy, xx = np.mgrid[0:96, 0:128]
+    arr = np.clip(128 + 100 * np.sin(yy / 9.0)[..., None] * np.cos(xx[..., None] / 7.0 + np.arange(3)), 0, 255).astype(np.uint8)
+    p = tmp_path / "img.png"
+    Image.fromarray(arr).save(p)
+    quality = (5, 40, 90)
+    res = utils.evaluate_compression_jpg(str(p), quality=quality, return_reconstructions=True)
+    assert res["BPP"].shape == (3,) and np.all(np.diff(res["BPP"]) > 0)
+    assert res["reconstructions"].shape == (3, 96, 128, 3)
+    xs = np.repeat(arr[None], 3, axis=0)
+    assert np.array_equal(res["MSE (RGB)"], o.image_mse(xs, res["reconstructions"]))
+    np.testing.assert_allclose(res["MS-SSIM (RGB)"], o.ms_ssim(xs, res["reconstructions"]), rtol=1e-12)
+    assert np.all(np.diff(res["PSNR (Luma)"]) > 0) and "MS-SSIM (Chroma) (dB)" in res
+    buf = BytesIO()
+    Image.open(p).convert("RGB").save(buf, "jpeg", quality=40)
+    assert res["BPP"][1] == buf.tell() * 8 / (96 * 128)

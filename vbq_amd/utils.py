@@ -101,6 +101,56 @@ def convert_to_db(d):
     return -10 * np.log10(1 - d)
 
 
+def _quality_by_mode(x, x_yc, x_hats, x_hats_yc):
+    """MSE / PSNR / MS-SSIM of M reconstructions against one image in the three colour modes of utils.py:574-597:
+    returns {'<metric> (<mode>)': float64 [M]}.  All M pairs of a mode go to the GPU as one batch."""
+    from . import metrics as img_comparison_metrics
+    M = len(x_hats)
+    out = {}
+    for mode in ("RGB", "Luma", "Chroma"):
+        if mode == "RGB":
+            x_comp, x_hats_comp = x, x_hats
+        elif mode == "Luma":
+            x_comp, x_hats_comp = x_yc[..., 0:1], x_hats_yc[..., 0:1]
+        else:
+            x_comp, x_hats_comp = x_yc[..., 1:], x_hats_yc[..., 1:]
+        xs_comp = np.repeat(np.ascontiguousarray(x_comp)[None, ...], repeats=M, axis=0)
+        x_hats_comp = np.ascontiguousarray(x_hats_comp)
+        out["MSE (%s)" % mode] = img_comparison_metrics.mse(xs_comp, x_hats_comp)
+        out["PSNR (%s)" % mode] = img_comparison_metrics.psnr(xs_comp, x_hats_comp, max_val=255)
+        out["MS-SSIM (%s)" % mode] = img_comparison_metrics.ms_ssim(xs_comp, x_hats_comp, max_val=255)
+    return out
+
+
+def evaluate_compression_jpg(img_file, quality=(1, 10), return_reconstructions=False, use_tf=False):
+    """utils.py:636-742: the JPEG baseline curve of one image -- PIL encodes at every quality setting (host, as in
+    the reference), the reconstructions are scored on the GPU.  Same result dict."""
+    from io import BytesIO
+
+    from PIL import Image
+    if use_tf:
+        raise VBQError("use_tf=True needs TensorFlow's image ops; this build evaluates mse / psnr / ms_ssim natively")
+    orig = Image.open(img_file)
+    img = orig.convert("RGB")
+    img_hats = []
+    file_sizes = np.empty(len(quality))
+    for i, qual in enumerate(quality):
+        buf = BytesIO()
+        img.save(buf, "jpeg", quality=qual)
+        file_sizes[i] = buf.tell()
+        img_hats.append(Image.open(buf).convert("RGB"))
+    num_pixels = orig.size[0] * orig.size[1]
+    results = {"BPP": file_sizes * 8 / num_pixels}
+    x, x_yc = np.asarray(img), np.asarray(img.convert("YCbCr"))
+    x_hats = np.array([np.asarray(h) for h in img_hats])
+    x_hats_yc = np.array([np.asarray(h.convert("YCbCr")) for h in img_hats])
+    if return_reconstructions:
+        results["reconstructions"] = x_hats
+    results.update(_quality_by_mode(x, x_yc, x_hats, x_hats_yc))
+    results.update({"%s (dB)" % k: convert_to_db(v) for k, v in results.items() if "MS-SSIM" in k})
+    return results
+
+
 def evaluate_compression_quantizer(quantizer, vae, test_img_files, settings, model_input_float_type="float32",
                                    return_reconstructions=False, use_tf=False):
     """utils.py:502-634: compress every image with `quantizer.compress(X, vae, settings, clip=True)` and report bits
@@ -110,8 +160,6 @@ def evaluate_compression_quantizer(quantizer, vae, test_img_files, settings, mod
     image are evaluated in one batch on the GPU (vbq_amd.metrics).  `use_tf=True` (TensorFlow's ssim ops) is not
     available."""
     from PIL import Image
-
-    from . import metrics as img_comparison_metrics
     if use_tf:
         raise VBQError("use_tf=True needs TensorFlow's image ops; this build evaluates mse / psnr / ms_ssim natively")
     N, M = len(test_img_files), len(settings)
@@ -145,17 +193,7 @@ def evaluate_compression_quantizer(quantizer, vae, test_img_files, settings, mod
         x_hats_yc = np.array([np.asarray(h.convert("YCbCr")) for h in img_hats])
         if return_reconstructions:
             results["reconstructions"].append(x_hats)
-        for mode in modes:
-            if mode == "RGB":
-                x_comp, x_hats_comp = x, x_hats
-            elif mode == "Luma":
-                x_comp, x_hats_comp = x_yc[..., 0:1], x_hats_yc[..., 0:1]
-            else:
-                x_comp, x_hats_comp = x_yc[..., 1:], x_hats_yc[..., 1:]
-            xs_comp = np.repeat(np.ascontiguousarray(x_comp)[None, ...], repeats=M, axis=0)
-            x_hats_comp = np.ascontiguousarray(x_hats_comp)
-            results["MSE (%s)" % mode][n] = img_comparison_metrics.mse(xs_comp, x_hats_comp)
-            results["PSNR (%s)" % mode][n] = img_comparison_metrics.psnr(xs_comp, x_hats_comp, max_val=255)
-            results["MS-SSIM (%s)" % mode][n] = img_comparison_metrics.ms_ssim(xs_comp, x_hats_comp, max_val=255)
+        for key, val in _quality_by_mode(x, x_yc, x_hats, x_hats_yc).items():
+            results[key][n] = val
     results.update({"%s (dB)" % k: convert_to_db(v) for k, v in results.items() if "MS-SSIM" in k})
     return results
