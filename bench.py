@@ -125,6 +125,9 @@ def main():
     ap.add_argument("--notebook", action="store_true",
                     help="C = 1 workloads in the word-embedding notebook's arithmetic (K1n: f64 squared error, penalty "
                          "fl32(2 beta sigma^2) * length, ipynb:429-443) instead of the image pipeline's f32 score")
+    ap.add_argument("--direct-bc", action="store_true",
+                    help="C > 1: let K1 read the channel-last inputs itself (VBQ_LAYOUT_BC_TO_CB) instead of transposing them "
+                         "into planes first; measured 1-2 %% slower end to end (K1 +36 us against 31 us of transposes)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step from a captured HIP graph (one GPU; per-kernel times come from an eager pass)")
     args = ap.parse_args()
@@ -210,12 +213,15 @@ def main():
         if works[slot] is not None:          # the all-reduce that last used this buffer must be done
             works[slot].wait()
             works[slot] = None
-        if mu_in is not None:
+        if mu_in is not None and not args.direct_bc:
             ops.transpose(mu_in, out=mu)
             ops.transpose(sg_in, out=sg)
         if i is not None:
             ev[i][0].record()
-        if args.notebook:
+        if mu_in is not None and args.direct_bc:
+            # K1 reads the latents as they arrive (channel-last) and writes channel-major planes
+            ops.quantize(mu_in, sg_in, tab, LAMBDAS, N=N_BITS, level_len=level_len, layout="bc->cb", out_idx=idx, workspace=ws)
+        elif args.notebook:
             ops.quantize_notebook(mu, sg, codebook, BETAS, N=N_BITS, want_values=False, out_idx=idx)
         else:
             ops.quantize(mu, sg, tab, LAMBDAS, N=N_BITS, level_len=level_len, layout=layout, out_idx=idx, workspace=ws)
@@ -327,7 +333,7 @@ def main():
                                       f"{L}-point lambda sweep 2**linspace(-8,7.5,32); ")
                                    + f"N={N_BITS} (2047 code points/channel); "
                                    f"{'raw' if args.raw_lengths or args.notebook else 'corrected'} code lengths; stage={args.stage} "
-                                   f"({'layout change + ' if C > 1 else ''}K1 solve{' + K2 histogram' + (' + RCCL all-reduce' if world > 1 else '') if args.stage == 'full' else ''})",
+                                   f"({'layout change + ' if C > 1 and not args.direct_bc else ''}K1 solve{' (channel-last in, planes out)' if C > 1 and args.direct_bc else ''}{' + K2 histogram' + (' + RCCL all-reduce' if world > 1 else '') if args.stage == 'full' else ''})",
                        "elements_per_gpu": E, "lambdas": L, "parallelism": f"element-sharded x{world}",
                        "launch": "hip graph replay" if args.graph else "eager launches"},
             "roofline": {"bound": "hbm", "kernel": "k_quant_notebook_fast" if args.notebook else "k_quant_fast",

@@ -52,7 +52,14 @@ enum {
     VBQ_ERR_WORKSPACE = -4
 };
 
-enum { VBQ_LAYOUT_BC = 0, VBQ_LAYOUT_CB = 1 };
+enum {
+    VBQ_LAYOUT_BC = 0,
+    VBQ_LAYOUT_CB = 1,
+    /* vbq_quantize_f32 only: inputs channel-last [n_rows][n_ch] as the latents arrive, outputs channel-major
+     * planes [n_lambda][n_ch][n_rows] -- the solve without the two input transposes (VBQ_MODE_F32, lambdas in
+     * the fast kernel's range; otherwise VBQ_ERR_UNSUPPORTED). */
+    VBQ_LAYOUT_BC_TO_CB = 2
+};
 
 /* Tie-break / arithmetic of the solve. */
 enum {

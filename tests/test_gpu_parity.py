@@ -361,3 +361,26 @@ def test_bit_depths_above_ten_on_planes(ops, Nbits):
     assert np.array_equal(cnt, CO.histogram(want_i, C, N=Nbits))
     with pytest.raises(VBQError, match="planes"):
         ops.quantize(dev(mu), dev(sg), dev(orc.all_code_points), lam, N=Nbits)
+
+
+@pytest.mark.parametrize("rows,C", [(1, 2), (513, 3), (1000, 16), (2047, 40), (4096, 256)])
+def test_channel_last_in_planes_out(ops, rows, C):
+    """VBQ_LAYOUT_BC_TO_CB: the fast kernel reads the latents channel-last and writes planes -- same indices, code
+    points and bits as transposing first; requests the fast kernel cannot serve are refused."""
+    from vbq_amd._lib import VBQError
+    rng = np.random.default_rng(rows + C)
+    orc = O.ChannelwiseOracle(C, N)
+    orc.build_code_points(O.factored_gaussian_icdf(np.zeros(C), np.exp(rng.uniform(-1, 1, C))))
+    mu = rng.normal(0, 1.3, (rows, C)).astype(np.float32)
+    sg = np.exp(rng.normal(-2, 0.8, (rows, C))).astype(np.float32)
+    lam = LAM32[::5]
+    ll = (np.arange(N + 1, dtype=np.float32)[None, None, :] + np.abs(rng.normal(0, 1, (len(lam), C, N + 1)))).astype(np.float32)
+    want = CO.quantize(mu, sg, orc.all_code_points, lam, N=N, level_len=ll, want_zhat=True, want_bits=True, threads=8)
+    got = ops.quantize(dev(mu), dev(sg), dev(orc.all_code_points), lam, N=N, level_len=dev(ll), layout="bc->cb", want_zhat=True,
+                       want_bits=True)
+    for g, w in zip(got, want):
+        assert g.shape == (len(lam), C, rows) and np.array_equal(host(g).transpose(0, 2, 1), w)
+    with pytest.raises(VBQError, match="fast f32 kernel"):
+        ops.quantize(dev(mu), dev(sg), dev(orc.all_code_points), [0.0, 1.0], N=N, layout="bc->cb")
+    with pytest.raises(VBQError, match="fast f32 kernel"):
+        ops.quantize(dev(mu), dev(sg), dev(orc.all_code_points), lam, N=N, layout="bc->cb", mode="f64")

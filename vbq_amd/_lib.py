@@ -12,7 +12,7 @@ c_f32p = C.c_void_p      # device pointers travel as integers
 c_u16p = C.c_void_p
 
 OK = 0
-LAYOUT_BC, LAYOUT_CB = 0, 1
+LAYOUT_BC, LAYOUT_CB, LAYOUT_BC_TO_CB = 0, 1, 2
 MODE_F32, MODE_F64_SCORE = 0, 1
 BMSHJ_PARAMS_PER_CHANNEL = 43
 

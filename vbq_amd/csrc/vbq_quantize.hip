@@ -332,7 +332,8 @@ int launch_quantize(const float *mu, const float *sg, int64_t n_rows, int32_t n_
     constexpr int N1 = N + 1;
     const int64_t E = n_rows * (int64_t)n_ch;
     PenT *pen = reinterpret_cast<PenT *>(ws);
-    const bool flat = (n_ch == 1) || (layout == VBQ_LAYOUT_CB);
+    const bool bc_to_cb = layout == VBQ_LAYOUT_BC_TO_CB && n_ch > 1;
+    const bool flat = (n_ch == 1) || (layout == VBQ_LAYOUT_CB) || bc_to_cb;
 
     for (int l0 = 0; l0 < L; l0 += kMaxLambdaChunk) {
         const int Lc = (L - l0 < kMaxLambdaChunk) ? (L - l0) : kMaxLambdaChunk;
@@ -366,10 +367,15 @@ int launch_quantize(const float *mu, const float *sg, int64_t n_rows, int32_t n_
             if constexpr (sizeof(PenT) == 4) {
                 if (fast_ok) {
                     const int r = launch_quant_fast<N>(mu, sg, n_per_ch, n_ch, table, pen, len_c, Lc, oi, oz, ob, E,
-                                                       vec_ok, st);
+                                                       vec_ok | (bc_to_cb ? 2 : 0), st);
                     if (r != VBQ_OK) return r;
                     continue;
                 }
+            }
+            if (bc_to_cb) {
+                set_error("vbq_quantize_f32: VBQ_LAYOUT_BC_TO_CB is served by the fast f32 kernel only (VBQ_MODE_F32, every "
+                          "lambda in [1.9e-12, 1.8e19]); transpose with vbq_transpose_f32 and use VBQ_LAYOUT_CB instead");
+                return VBQ_ERR_UNSUPPORTED;
             }
             hipLaunchKernelGGL((k_quant_flat<N, PenT>), dim3((unsigned)gx, (unsigned)n_ch), dim3(256), 0, st, mu, sg,
                                (long)n_per_ch, (int)n_ch, table, pen, len_c, Lc, oi, oz, ob, (long)E, vec_ok);
@@ -425,7 +431,7 @@ extern "C" int vbq_quantize_f32(const float *d_mu, const float *d_sigma, int64_t
                 "vbq_quantize_f32: bad sizes n_rows=%lld n_ch=%d n_lambda=%d", (long long)n_rows, n_ch, n_lambda);
     VBQ_REQUIRE(n_rows == 0 || (d_mu && d_sigma && d_table_lm && h_lambdas && d_out_idx), VBQ_ERR_INVALID_ARGUMENT,
                 "vbq_quantize_f32: null pointer argument");
-    VBQ_REQUIRE(layout == VBQ_LAYOUT_BC || layout == VBQ_LAYOUT_CB, VBQ_ERR_INVALID_ARGUMENT,
+    VBQ_REQUIRE(layout == VBQ_LAYOUT_BC || layout == VBQ_LAYOUT_CB || layout == VBQ_LAYOUT_BC_TO_CB, VBQ_ERR_INVALID_ARGUMENT,
                 "vbq_quantize_f32: unknown layout %d", layout);
     VBQ_REQUIRE(mode == VBQ_MODE_F32 || mode == VBQ_MODE_F64_SCORE, VBQ_ERR_INVALID_ARGUMENT,
                 "vbq_quantize_f32: unknown mode %d", mode);

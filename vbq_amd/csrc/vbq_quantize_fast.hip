@@ -173,9 +173,19 @@ k_quant_fast(const float *__restrict__ mu, const float *__restrict__ sg, long n_
 
     for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < nquads; q += (long)gridDim.x * blockDim.x) {
         const long i0 = q * NE;
-        const bool full = vec_ok && (i0 + NE <= n_per_ch);
+        const bool full = (vec_ok & 1) && (i0 + NE <= n_per_ch);
         float m4[NE], s4[NE];
-        if (full) {
+        if (vec_ok & 2) {
+            // channel-last input [n_per_ch][C] (VBQ_LAYOUT_BC_TO_CB): element (row, c) at row * C + c.  The lanes
+            // of a wave read 4 bytes from 128 different lines, but the 32 channels of a line are read by 32
+            // workgroups in flight together, so the lines come out of L2; the outputs are planes as usual.
+#pragma unroll
+            for (int k = 0; k < NE; ++k) {
+                const bool ok = i0 + k < n_per_ch;
+                m4[k] = ok ? mu[(i0 + k) * C + c] : 0.0f;
+                s4[k] = ok ? sg[(i0 + k) * C + c] : 1.0f;
+            }
+        } else if (full) {
             if constexpr (NE == 4) {
                 const float4 mv = *reinterpret_cast<const float4 *>(mu + base + i0);
                 const float4 sv = *reinterpret_cast<const float4 *>(sg + base + i0);

@@ -9,7 +9,7 @@ from typing import Optional, Sequence
 import torch
 
 from . import _lib
-from ._lib import LAYOUT_BC, LAYOUT_CB, MODE_F32, MODE_F64_SCORE, VBQError, check
+from ._lib import LAYOUT_BC, LAYOUT_BC_TO_CB, LAYOUT_CB, MODE_F32, MODE_F64_SCORE, VBQError, check
 
 _LAYOUTS = {"bc": LAYOUT_BC, "cb": LAYOUT_CB, LAYOUT_BC: LAYOUT_BC, LAYOUT_CB: LAYOUT_CB}
 _MODES = {"f32": MODE_F32, "f64": MODE_F64_SCORE, MODE_F32: MODE_F32, MODE_F64_SCORE: MODE_F64_SCORE}
@@ -58,8 +58,11 @@ def quantize(mu: torch.Tensor, sigma: torch.Tensor, table_lm: torch.Tensor, lamb
              workspace: Optional[torch.Tensor] = None):
     """K1 (vbq_quantize_f32).  mu, sigma: f32 [rows, C] (layout 'bc') / [C, rows] ('cb') / [n] (C = 1).
     table_lm: f32 [C, T] level-major.  level_len: optional f32 [L, C, N+1].
-    Returns idx u16 [L, *mu.shape] and, when asked, zhat / bits f32 of the same shape."""
-    layout = _LAYOUTS[layout]
+    Returns idx u16 [L, *mu.shape] and, when asked, zhat / bits f32 of the same shape.
+    layout 'bc->cb': inputs channel-last [rows, C], outputs channel-major planes [L, C, rows] (no input transposes;
+    f32 mode and lambdas in the fast kernel's range only, VBQError otherwise)."""
+    to_planes = layout in ("bc->cb", LAYOUT_BC_TO_CB)
+    layout = LAYOUT_BC if to_planes else _LAYOUTS[layout]
     mode = _MODES[mode]
     mu = _dev(mu, torch.float32, "mu")
     sigma = _dev(sigma, torch.float32, "sigma")
@@ -78,7 +81,10 @@ def quantize(mu: torch.Tensor, sigma: torch.Tensor, table_lm: torch.Tensor, lamb
         if tuple(level_len.shape) != (L, Cc, N + 1):
             raise ValueError(f"level_len shape {tuple(level_len.shape)} != {(L, Cc, N + 1)}")
     h = _lib.lib()
-    oshape = (L,) + tuple(mu.shape)
+    if to_planes and mu.dim() == 2 and Cc > 1:
+        layout, oshape = LAYOUT_BC_TO_CB, (L, Cc, rows)
+    else:
+        oshape = (L,) + tuple(mu.shape)
 
     def _out(given, dtype, want, name):
         if given is not None:
