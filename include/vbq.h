@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define VBQ_ABI_VERSION 1
+#define VBQ_ABI_VERSION 2
 
 enum {
     VBQ_OK = 0,
@@ -93,7 +93,9 @@ int vbq_device_name(int dev, char *buf, size_t buflen);
  *   d_table_lm      f32 [n_ch][T] level-major, non-decreasing in xi for every channel.
  *   d_level_len     f32 [n_lambda][n_ch][N+1] code length of bit-level n (the
  *                   "n + overhead" of quantizer.py:171-175), or NULL for the raw
- *                   lengths n (quantizer.py:167-169).
+ *                   lengths n (quantizer.py:167-169).  Lengths are non-negative; when some
+ *                   lambda*len falls outside {0} U [2^-39, 2^70] the solve detects it on the
+ *                   device and takes its literal (slower) scan, with the same answers.
  *   h_lambdas       HOST doubles [n_lambda]; VBQ_MODE_F32 rounds each to f32 first
  *                   (TF casts the Python scalar to the tensor dtype).
  *   d_out_idx       u16 [n_lambda][n_rows*n_ch] rank index of the winner.
@@ -160,6 +162,11 @@ int vbq_histogram_u16(const uint16_t *d_idx, int64_t n_rows, int32_t n_ch, int32
  * all ranks whose histograms will be summed into this buffer) is below 2^31. */
 int vbq_histogram_u16_i32(const uint16_t *d_idx, int64_t n_rows, int32_t n_ch, int32_t layout,
                           int32_t n_lambda, int32_t N, int32_t *d_counts, void *stream);
+
+/* Largest index of a u16 index array (d_max: u32, device, MAX-ed into; zero it first).  K2 and the gather are
+ * memory-safe for any u16 input (indices >= T are counted in a wrapped bin / read the last table entry); a
+ * caller holding indices that did not come from K1 (a file, a decoder) checks max < T with this first. */
+int vbq_index_max_u16(const uint16_t *d_idx, int64_t n, uint32_t *d_max, void *stream);
 
 /* ----------------------------------------------------------------------------------
  * K3  Moment pass.  Replaces empirical_std = sqrt(mean(mu^2)) (ipynb:373-374) and the
@@ -235,16 +242,25 @@ int vbq_bmshj_nll_grad_f32(const float *d_params, const float *d_x_cb, int64_t n
  * ---------------------------------------------------------------------------------- */
 int vbq_rans_encode_u16(const uint16_t *d_idx, int64_t n_streams, int64_t n, int32_t N, int32_t seg,
                         const uint16_t *d_freq, uint16_t *d_words, uint32_t *d_sizes, void *stream);
+/* Decoding treats words / sizes as UNTRUSTED: no read leaves a segment's seg + 2 words, every decoded index is
+ * below T, and d_status (u32, device, may be NULL; OR-ed into, zero it first) reports what was wrong --
+ * bit 0 a segment size outside [2, seg + 2], bit 1 a segment that ran out of words, bit 2 words left over or a
+ * wrong final state (a damaged stream), bit 3 a frequency row that does not sum to 2^15.  Segments with bits 0 / 3
+ * decode to zeros. */
 int vbq_rans_decode_u16(const uint16_t *d_words, const uint32_t *d_sizes, int64_t n_streams, int64_t n,
-                        int32_t N, int32_t seg, const uint16_t *d_freq, uint16_t *d_idx, void *stream);
+                        int32_t N, int32_t seg, const uint16_t *d_freq, uint16_t *d_idx, uint32_t *d_status,
+                        void *stream);
 
 /* ----------------------------------------------------------------------------------
  * Packed counters for the histogram all-reduce: three 21-bit fields per int64 word.
  * An integer SUM all-reduce of the words adds the fields independently while every GLOBAL count is
- * below 2^21 (the caller checks: global rows per channel < 2097152), at 2.67 instead of 4 bytes per
- * bin on the wire.  n bins <-> (n + 2) / 3 words.
+ * below 2^21, at 2.67 instead of 4 bytes per bin on the wire.  n bins <-> (n + 2) / 3 words.
+ * Guard: *d_overflow (u32, device, may be NULL; OR-ed into, zero it first) is set to 1 when a LOCAL count is
+ * negative or >= 2^21 / n_ranks -- while it stays 0 on every rank the sum over n_ranks ranks cannot carry from one
+ * field into the next.  The caller checks the flag before trusting the unpacked sums.
  * ---------------------------------------------------------------------------------- */
-int vbq_pack_counts_3x21(const int32_t *d_counts, int64_t n, int64_t *d_words, void *stream);
+int vbq_pack_counts_3x21(const int32_t *d_counts, int64_t n, int64_t *d_words, int32_t n_ranks,
+                         uint32_t *d_overflow, void *stream);
 int vbq_unpack_counts_3x21(const int64_t *d_words, int64_t n, int32_t *d_counts, void *stream);
 
 /* ----------------------------------------------------------------------------------

@@ -44,7 +44,7 @@ def test_ctypes_binding_matches_header(built_lib):
     from vbq_amd import _lib
     assert sorted(_lib.SIGNATURES) == declared_functions()
     h = _lib.lib()
-    assert h.vbq_abi_version() == 1
+    assert h.vbq_abi_version() == 2
     assert isinstance(h.vbq_device_count(), int)
     # argument validation happens before any device work: callable without a GPU
     assert h.vbq_quantize_workspace_bytes(256, 32, 10) >= 256 * 32 * 11 * 4
@@ -84,6 +84,7 @@ def test_argument_validation_of_the_newer_entry_points(built_lib):
     assert h.vbq_ssim_scale_f64(None, None, 1, 8, 8, 1, None, 12, C.c_double(1), C.c_double(1), None, None, None, 0, None) == -1
     assert b"window" in h.vbq_last_error()
     assert h.vbq_image_sqerr_u8(None, None, -1, 4, None, None) == -1
-    assert h.vbq_pack_counts_3x21(None, -1, None, None) == -1 and h.vbq_pack_counts_3x21(None, 0, None, None) == 0
+    assert h.vbq_pack_counts_3x21(None, -1, None, 1, None, None) == -1 and h.vbq_pack_counts_3x21(None, 0, None, 1, None, None) == 0
+    assert h.vbq_pack_counts_3x21(None, 3, None, 0, None, None) == -1 and b"n_ranks" in h.vbq_last_error()
     assert h.vbq_downsample2_f64(None, 1, 0, 4, 1, None, None) == -1
     assert h.vbq_transpose_f32(None, 4, 4, None, None) == -1

@@ -93,3 +93,48 @@ def test_rans_on_real_quantizer_output():
     bits = codec.compressed_bits(sizes)
     assert bits <= 1.02 * est + 40 * sizes.numel()
     assert bits >= 0.98 * est
+
+
+@pytest.mark.gpu
+def test_rans_decode_rejects_damaged_streams():
+    """The decoder treats words / sizes as untrusted: out-of-range segment sizes, truncated segments, flipped
+    words and foreign frequency tables raise VBQError (no out-of-bounds read, no silently wrong symbols), and a
+    histogram / gather of arbitrary u16 indices stays inside its tables."""
+    if not torch.cuda.is_available():
+        pytest.fail("gpu-marked test run without a ROCm device")
+    from vbq_amd import _lib, ops
+    from vbq_amd.coder import RansCodec, quantize_frequencies
+    rng = np.random.default_rng(9)
+    S, n, seg = 4, 5000, 512
+    idx = _streams(rng, S, n, [0.5, 3.0, 30.0, 200.0])
+    counts = np.stack([np.bincount(r, minlength=T) for r in idx])
+    codec = RansCodec(quantize_frequencies(counts), N=N, segment=seg)
+    words, sizes = codec.encode(torch.from_numpy(idx).cuda())
+    assert torch.equal(codec.decode(words, sizes, n).cpu(), torch.from_numpy(idx))
+    for bad_size in (0, 1, seg + 3, 0xffffffff):
+        s2 = sizes.clone()
+        s2.view(torch.int32)[1, 2] = np.int64(bad_size).astype(np.int32) if bad_size > 0x7fffffff else bad_size
+        with pytest.raises(_lib.VBQError, match="segment size"):
+            codec.decode(words, s2, n)
+    s2 = sizes.clone()                                                    # a truncated segment: fewer words than it needs
+    s2.view(torch.int32)[0, 0] = 2
+    with pytest.raises(_lib.VBQError, match="ran out of words|final state"):
+        codec.decode(words, s2, n)
+    w2 = words.clone()                                                    # flipped payload bits
+    w2.view(torch.int16)[2, 1, :8] ^= 0x5a5a
+    with pytest.raises(_lib.VBQError):
+        codec.decode(w2, sizes, n)
+    other = RansCodec(quantize_frequencies(counts[::-1].copy()), N=N, segment=seg)    # decoded with another model
+    with pytest.raises(_lib.VBQError):
+        other.decode(words, sizes, n)
+    with pytest.raises(ValueError):
+        codec.decode(words[:, :-1], sizes, n)
+    # arbitrary u16 "indices" (not produced by K1): memory-safe, and vbq_index_max_u16 tells the caller
+    junk = torch.from_numpy(rng.integers(0, 65536, (2, 3, 4096)).astype(np.uint16)).cuda()
+    assert ops.index_max(junk) == int(junk.cpu().numpy().max())
+    cnt = ops.histogram(junk, 3, N=N, layout="cb")
+    assert int(cnt.sum().item()) == junk.numel()
+    tab = torch.arange(3 * T, dtype=torch.float32, device="cuda").reshape(3, T)
+    got = ops.gather(junk, tab, 3, N=N, layout="cb").cpu().numpy()
+    ref = (np.arange(3)[None, :, None] * T + np.minimum(junk.cpu().numpy().astype(np.int64), T - 1)).astype(np.float32)
+    assert np.array_equal(got, ref)

@@ -85,7 +85,9 @@ def test_pack_counts_round_trip_and_field_sums():
         words = []
         for c in parts:
             w = torch.empty((n + 2) // 3, dtype=torch.int64, device="cuda")
-            _lib.check(h.vbq_pack_counts_3x21(ops._ptr(c), n, ops._ptr(w), ops._stream(c)), "pack")
+            flag = torch.zeros(1, dtype=torch.uint32, device="cuda")
+            _lib.check(h.vbq_pack_counts_3x21(ops._ptr(c), n, ops._ptr(w), 8, ops._ptr(flag), ops._stream(c)), "pack")
+            assert int(flag.cpu().item()) == 0
             back = torch.empty_like(c)
             _lib.check(h.vbq_unpack_counts_3x21(ops._ptr(w), n, ops._ptr(back), ops._stream(c)), "unpack")
             assert torch.equal(back, c)
@@ -94,6 +96,22 @@ def test_pack_counts_round_trip_and_field_sums():
         out = torch.empty(n, dtype=torch.int32, device="cuda")
         _lib.check(h.vbq_unpack_counts_3x21(ops._ptr(total), n, ops._ptr(out), ops._stream(out)), "unpack")
         assert torch.equal(out, torch.stack(parts).sum(0).to(torch.int32))
+
+
+def test_pack_counts_overflow_guard():
+    """A local count at or above 2^21 / n_ranks (or negative) raises the device flag; below it the flag stays 0."""
+    if not torch.cuda.is_available():
+        pytest.fail("gpu-marked test run without a ROCm device")
+    from vbq_amd import _lib, ops
+    h = _lib.lib()
+    for world, bad, pos in ((2, 1 << 20, 5), (8, (1 << 21) // 8, 0), (1, -1, 7), (4, (1 << 21) // 4 - 1, 3)):
+        c = torch.full((10,), 5, dtype=torch.int32, device="cuda")
+        c[pos] = bad
+        w = torch.empty(4, dtype=torch.int64, device="cuda")
+        flag = torch.zeros(1, dtype=torch.uint32, device="cuda")
+        _lib.check(h.vbq_pack_counts_3x21(ops._ptr(c), 10, ops._ptr(w), world, ops._ptr(flag), ops._stream(c)), "pack")
+        expect = 0 if (0 <= bad < (1 << 21) // world) else 1
+        assert int(flag.cpu().item()) == expect, (world, bad)
 
 
 def _reduce_worker(rank, world, port, out):
@@ -109,9 +127,20 @@ def _reduce_worker(rank, world, port, out):
     for limit in (1000, 1 << 22):                                   # packed and plain int32 paths
         c = torch.from_numpy(rng.integers(0, 400, (3, 4, 2047)).astype(np.int32)).to(dev)
         red = CountsAllReduce(c.numel(), dev, max_global_count=limit)
-        red.start(c).wait()
+        red.start(c).wait(check=True)
         torch.cuda.synchronize()
         res.append((red.packed, c.cpu().numpy()))
+    # a count that could carry into the next field: every rank must see the flag (rank 1 alone holds the count)
+    c = torch.full((6,), 3, dtype=torch.int32, device=dev)
+    if rank == 1:
+        c[2] = 1 << 20
+    red = CountsAllReduce(c.numel(), dev, max_global_count=1000)
+    red.start(c).wait()
+    try:
+        red.check()
+        res.append("no error")
+    except Exception as e:
+        res.append(type(e).__name__)
     out.put((rank, res))
     dist.barrier()
     dist.destroy_process_group()
@@ -141,6 +170,7 @@ def test_counts_all_reduce_packed_equals_plain():
         want.append(arrs[0] + arrs[1])
     for r in range(2):
         assert res[r][0][0] is True and res[r][1][0] is False
+        assert res[r][2] == "VBQError"
         for i in range(2):
             assert np.array_equal(res[r][i][1], want[i])
 

@@ -12,6 +12,7 @@ c_f32p = C.c_void_p      # device pointers travel as integers
 c_u16p = C.c_void_p
 
 OK = 0
+ABI_VERSION = 2
 LAYOUT_BC, LAYOUT_CB, LAYOUT_BC_TO_CB = 0, 1, 2
 MODE_F32, MODE_F64_SCORE = 0, 1
 BMSHJ_PARAMS_PER_CHANNEL = 43
@@ -32,6 +33,7 @@ SIGNATURES = {
                                     C.c_void_p]),
     "vbq_histogram_u16_i32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                         C.c_void_p, C.c_void_p]),
+    "vbq_index_max_u16": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "vbq_moments_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "vbq_gather_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                  C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
@@ -56,12 +58,12 @@ SIGNATURES = {
     "vbq_ssim_scale_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
                                      C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "vbq_downsample2_f64": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
-    "vbq_pack_counts_3x21": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "vbq_pack_counts_3x21": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "vbq_unpack_counts_3x21": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "vbq_rans_encode_u16": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p]),
     "vbq_rans_decode_u16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p,
-                                      C.c_void_p, C.c_void_p]),
+                                      C.c_void_p, C.c_void_p, C.c_void_p]),
     "vbq_bmshj_nll_grad_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
 }
 
@@ -96,8 +98,8 @@ def lib():
             raise VBQError(f"{path} does not export {name}; rebuild with `python -m vbq_amd.build --force`") from e
         fn.restype = res
         fn.argtypes = args
-    if h.vbq_abi_version() != 1:
-        raise VBQError(f"{path}: ABI version {h.vbq_abi_version()} != 1")
+    if h.vbq_abi_version() != ABI_VERSION:
+        raise VBQError(f"{path}: ABI version {h.vbq_abi_version()} != {ABI_VERSION}; rebuild with `python -m vbq_amd.build --force`")
     _LIB = h
     return h
 

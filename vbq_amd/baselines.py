@@ -16,6 +16,11 @@ from ._lib import VBQError, check
 def _dev_f32(a):
     if not torch.cuda.is_available():
         raise VBQError("no ROCm device visible: vbq_amd.baselines has no CPU implementation")
+    dt = a.dtype if isinstance(a, (torch.Tensor, np.ndarray)) else np.asarray(a).dtype
+    if dt in (torch.float64, np.float64) and not isinstance(a, (list, tuple)):
+        # the reference would bin float64 samples in float64 (floor((x - min) / delta), vq.vq); the kernels are f32
+        raise ValueError("float64 samples are not supported: the comparison quantizers run in float32, the dtype of the "
+                         "latents they are applied to (cast explicitly if f32 binning is what you want)")
     t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=np.float32)))
     return t.to(torch.device("cuda", torch.cuda.current_device()), torch.float32).contiguous().reshape(-1)
 

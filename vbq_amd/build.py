@@ -21,7 +21,8 @@ LIB = os.path.join(LIBDIR, "libvbq_hip.so")
 INCLUDE = os.path.join(ROOT, "include")
 HIP_SOURCES = ["vbq_api.hip", "vbq_quantize.hip", "vbq_quantize_fast.hip", "vbq_hist.hip", "vbq_notebook.hip", "vbq_bmshj.hip",
                "vbq_candidates.hip", "vbq_rans.hip", "vbq_baselines.hip", "vbq_ranks.hip", "vbq_metrics.hip"]
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+LINK_LIBS = []
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
                # every f32/f64 op of the reference is a separately rounded op: never contract a*b+c
                "-ffp-contract=off", "-fno-fast-math"]
 
@@ -37,23 +38,46 @@ def hip_sources():
     return [os.path.join(CSRC, s) for s in HIP_SOURCES if os.path.exists(os.path.join(CSRC, s))]
 
 
+def _compile_one(hipcc, src, obj, extra):
+    cmd = [hipcc] + HIPCC_FLAGS + extra + ["-I", INCLUDE, "-I", CSRC, "-c", src, "-o", obj + ".tmp"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed on " + os.path.basename(src) + ":\n" + r.stdout + r.stderr)
+    os.replace(obj + ".tmp", obj)
+    return " ".join(cmd)
+
+
 def build_hip(force: bool = False, verbose: bool = False) -> str:
+    """One object per .hip source (rebuilt only when it or a header changed, in parallel), one link."""
+    from concurrent.futures import ThreadPoolExecutor
     srcs = hip_sources()
-    deps = srcs + [os.path.join(CSRC, "vbq_common.h"), os.path.join(INCLUDE, "vbq.h")]
-    if not force and not _newer(LIB, deps):
+    headers = [os.path.join(CSRC, "vbq_common.h"), os.path.join(INCLUDE, "vbq.h")]
+    extra = os.environ.get("VBQ_EXTRA_HIPCC_FLAGS", "").split()       # developer experiments only
+    objdir = os.path.join(LIBDIR, "obj")
+    flags_tag = os.path.join(objdir, "flags.txt")
+    tag = " ".join(HIPCC_FLAGS + extra)
+    os.makedirs(objdir, exist_ok=True)
+    if not os.path.exists(flags_tag) or open(flags_tag).read() != tag:
+        force = True
+    objs = [os.path.join(objdir, os.path.basename(s)[:-4] + ".o") for s in srcs]
+    todo = [(s, o) for s, o in zip(srcs, objs) if force or _newer(o, [s] + headers)]
+    if not todo and not _newer(LIB, objs):
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build libvbq_hip.so (ROCm toolchain required)")
-    os.makedirs(LIBDIR, exist_ok=True)
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        for line in ex.map(lambda so: _compile_one(hipcc, so[0], so[1], extra), todo):
+            if verbose:
+                print(line)
+    open(flags_tag, "w").write(tag)
     tmp = LIB + ".tmp"
-    extra = os.environ.get("VBQ_EXTRA_HIPCC_FLAGS", "").split()       # developer experiments only
-    cmd = [hipcc] + HIPCC_FLAGS + extra + ["-I", INCLUDE, "-I", CSRC] + srcs + ["-o", tmp]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + LINK_LIBS + ["-o", tmp]
     if verbose:
         print(" ".join(cmd))
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
+        raise RuntimeError("link failed:\n" + r.stdout + r.stderr)
     os.replace(tmp, LIB)
     return LIB
 

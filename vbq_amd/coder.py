@@ -96,13 +96,25 @@ class RansCodec:
         return words, sizes
 
     def decode(self, words: torch.Tensor, sizes: torch.Tensor, n: int) -> torch.Tensor:
+        """words / sizes are untrusted (they may come from a file): shapes are checked here, segment sizes and
+        word counts in the kernel; a damaged stream raises VBQError instead of returning garbage."""
         words = ops._dev(words, torch.uint16, "words")
         sizes = ops._dev(sizes, torch.uint32, "sizes")
         S = self.freq_host.shape[0]
+        nseg = (n + self.segment - 1) // self.segment
+        if words.numel() != S * nseg * (self.segment + 2) or sizes.numel() != S * nseg:
+            raise ValueError(f"expected words [{S}, {nseg}, {self.segment + 2}] and sizes [{S}, {nseg}] for {n} symbols per "
+                             f"stream, got {tuple(words.shape)} and {tuple(sizes.shape)}")
         idx = torch.empty((S, n), dtype=torch.uint16, device=words.device)
+        status = torch.zeros(1, dtype=torch.uint32, device=words.device)
         check(_lib.lib().vbq_rans_decode_u16(ops._ptr(words), ops._ptr(sizes), S, n, self.N, self.segment,
-                                             ops._ptr(self._freq(words.device)), ops._ptr(idx), ops._stream(words)),
-              "vbq_rans_decode_u16")
+                                             ops._ptr(self._freq(words.device)), ops._ptr(idx), ops._ptr(status),
+                                             ops._stream(words)), "vbq_rans_decode_u16")
+        st = int(status.cpu().item())
+        if st:
+            what = [m for b, m in ((1, "segment size out of range"), (2, "segment ran out of words"),
+                                   (4, "left-over words / wrong final state"), (8, "invalid frequency table")) if st & b]
+            raise _lib.VBQError("rANS bitstream rejected: " + ", ".join(what))
         return idx
 
     @staticmethod

@@ -46,6 +46,6 @@ __device__ __forceinline__ float neg_half_sq_err(float P, float mu, float sigma)
 template <int N>
 int launch_quant_fast(const float *mu, const float *sg, int64_t n_per_ch, int32_t n_ch, const float *table,
                       const float *pen, const float *len, int32_t L, uint16_t *out_idx, float *out_zhat,
-                      float *out_bits, int64_t E, int vec_ok, hipStream_t st);
+                      float *out_bits, int64_t E, int vec_ok, const unsigned int *odd_pen, hipStream_t st);
 
 }  // namespace vbq

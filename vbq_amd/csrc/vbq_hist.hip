@@ -21,7 +21,10 @@ constexpr int kHistThreads = 256;
 // q = 31 (mod 32) -- one LDS bank -- and those are exactly the bins that fill up at large
 // lambda.  q ^ (q >> 6) is a bijection of [0, 2^11) that spreads every level evenly over the
 // 32 banks (measured: the histogram pass went from 0.65 ms to the load-bound time).
-__device__ __forceinline__ unsigned int bin_slot(unsigned int q) { return q ^ (q >> 6); }
+// Indices that did not come from K1 may be anything up to 65535: the slot is masked into the 8192-word bin
+// array (memory-safe, counts of such indices are meaningless -- vbq_index_max_u16 tells the caller beforehand).
+template <int N>
+__device__ __forceinline__ unsigned int bin_slot(unsigned int q) { return (q ^ (q >> 6)) & ((2u << N) - 1u); }
 
 // Eight indices of one thread (one 16-B load) into the LDS histogram.
 // An LDS atomic wave-instruction costs ~3 cycles per lane that shares a bank with another
@@ -37,15 +40,15 @@ __host__ __device__ constexpr int hist_copies(int T) { return 8192 / hist_slots(
 // The copies of a bin are adjacent words (word = 4 * slot + copy): lanes of different copies never meet on a
 // bank, and zeroing / flushing the 32 KB moves 16 bytes per LDS instruction.
 
-template <int kHistCopies>
+template <int N, int kHistCopies>
 __device__ __forceinline__ void hist_add8(unsigned int *h, const uint4 v) {
     unsigned int s[8];
     {
         const unsigned int w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            s[2 * k] = bin_slot(w[k] & 0xffffu);
-            s[2 * k + 1] = bin_slot(w[k] >> 16);
+            s[2 * k] = bin_slot<N>(w[k] & 0xffffu);
+            s[2 * k + 1] = bin_slot<N>(w[k] >> 16);
         }
     }
     unsigned int cnt = 1;
@@ -110,7 +113,7 @@ k_hist_flat(const uint16_t *__restrict__ idx, long n_per_ch, int C, long E,
             q += U * stride;
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) hist_add8<kHistCopies>(h, A[u]);
+        for (int u = 0; u < U; ++u) hist_add8<N, kHistCopies>(h, A[u]);
         if (!haveB) break;
         haveA = full(q, U);
         if (haveA) {
@@ -119,32 +122,32 @@ k_hist_flat(const uint16_t *__restrict__ idx, long n_per_ch, int C, long E,
             q += U * stride;
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) hist_add8<kHistCopies>(h, B[u]);
+        for (int u = 0; u < U; ++u) hist_add8<N, kHistCopies>(h, B[u]);
     }
-    for (; full(q, 1); q += stride) hist_add8<kHistCopies>(h, *reinterpret_cast<const uint4 *>(src + q * 8));
+    for (; full(q, 1); q += stride) hist_add8<N, kHistCopies>(h, *reinterpret_cast<const uint4 *>(src + q * 8));
     for (; q < noct; q += stride) {
         const uint4 v = *reinterpret_cast<const uint4 *>(src + q * 8);
         const unsigned int w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            atomicAdd(&h[kHistCopies * bin_slot(w[k] & 0xffffu)], 1u);
-            atomicAdd(&h[kHistCopies * bin_slot(w[k] >> 16)], 1u);
+            atomicAdd(&h[kHistCopies * bin_slot<N>(w[k] & 0xffffu)], 1u);
+            atomicAdd(&h[kHistCopies * bin_slot<N>(w[k] >> 16)], 1u);
         }
     }
     for (long i = noct * 8 + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n_per_ch; i += stride)
-        atomicAdd(&h[kHistCopies * bin_slot(src[i])], 1u);
+        atomicAdd(&h[kHistCopies * bin_slot<N>(src[i])], 1u);
     __syncthreads();
     CountT *dst = counts + ((long)l * C + c) * T;
     for (int i = threadIdx.x; i < T; i += blockDim.x) {
         unsigned int v;
         if constexpr (kHistCopies == 4) {
-            const uint4 q4 = reinterpret_cast<const uint4 *>(h)[bin_slot(i)];
+            const uint4 q4 = reinterpret_cast<const uint4 *>(h)[bin_slot<N>(i)];
             v = (q4.x + q4.y) + (q4.z + q4.w);
         } else if constexpr (kHistCopies == 2) {
-            const uint2 q2 = reinterpret_cast<const uint2 *>(h)[bin_slot(i)];
+            const uint2 q2 = reinterpret_cast<const uint2 *>(h)[bin_slot<N>(i)];
             v = q2.x + q2.y;
         } else {
-            v = h[bin_slot(i)];
+            v = h[bin_slot<N>(i)];
         }
         if (v) atomicAdd(&dst[i], (CountT)v);
     }
@@ -169,12 +172,12 @@ k_hist_tiled(const uint16_t *__restrict__ idx, long n_rows, int C, long E,
     const uint16_t *src = idx + (long)l * E;
     if (cl < ncg) {
         for (long r = (long)blockIdx.x * 64 + slot; r < n_rows; r += (long)gridDim.x * 64)
-            atomicAdd(&hs[cl * TS + bin_slot(src[r * C + c0 + cl])], 1u);
+            atomicAdd(&hs[cl * TS + bin_slot<N>(src[r * C + c0 + cl])], 1u);
     }
     __syncthreads();
     for (int i = threadIdx.x; i < ncg * T; i += blockDim.x) {
         const int ch = i / T, s = i - ch * T;
-        const unsigned int v = hs[ch * TS + bin_slot(s)];
+        const unsigned int v = hs[ch * TS + bin_slot<N>(s)];
         if (v) atomicAdd(&counts[((long)l * C + c0 + ch) * T + s], (CountT)v);
     }
 }
@@ -201,15 +204,13 @@ int launch_hist(const uint16_t *idx, int64_t n_rows, int32_t n_ch, int32_t layou
     } else {
         constexpr int T = table_size(N);
         const size_t lds = sizeof(unsigned int) * kTileChannels * (T + 2);
-        static bool attr_set = false;
-        if (!attr_set) {
+        {   // per device and cheap: set on every call (a process may drive several GPUs)
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hist_tiled<N, CountT>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) {
                 set_error("hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
                 return VBQ_ERR_LAUNCH;
             }
-            attr_set = true;
         }
         const int groups = (n_ch + kTileChannels - 1) / kTileChannels;
         int64_t gx = 512 / ((int64_t)groups * L) + 1;
@@ -313,7 +314,7 @@ k_gather(const uint16_t *__restrict__ idx, long n_rows, int C, int layout, long 
     const float *tl = tab + (per_lambda ? (long)l * C * T : 0);
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (long)gridDim.x * blockDim.x) {
         const int c = (C == 1) ? 0 : (layout == VBQ_LAYOUT_BC ? (int)(e % C) : (int)(e / n_rows));
-        dst[e] = tl[(long)c * T + src[e]];
+        dst[e] = tl[(long)c * T + min((int)src[e], T - 1)];     // foreign indices >= T stay inside the table
     }
 }
 
@@ -334,7 +335,7 @@ k_gather_transpose(const uint16_t *__restrict__ idx, long in_rows, long in_cols,
         const long r = r0 + ty + 8 * k, c = c0 + tx;
         if (r < in_rows && c < in_cols) {
             const int ch = in_layout == VBQ_LAYOUT_CB ? (int)r : (int)c;
-            tile[ty + 8 * k][tx] = tl[(long)ch * T + src[r * in_cols + c]];
+            tile[ty + 8 * k][tx] = tl[(long)ch * T + min((int)src[r * in_cols + c], T - 1)];
         }
     }
     __syncthreads();
@@ -442,14 +443,19 @@ extern "C" int vbq_histogram_u16_i32(const uint16_t *d_idx, int64_t n_rows, int3
 namespace vbq {
 namespace {
 __global__ void __launch_bounds__(256)
-k_pack3x21(const int32_t *__restrict__ c, long n, long nw, unsigned long long *__restrict__ w) {
+k_pack3x21(const int32_t *__restrict__ c, long n, long nw, unsigned long long *__restrict__ w, unsigned int limit,
+           unsigned int *__restrict__ overflow) {
+    bool over = false;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nw; i += (long)gridDim.x * blockDim.x) {
         const long b = 3 * i;
-        const unsigned long long f0 = (unsigned int)c[b];
-        const unsigned long long f1 = b + 1 < n ? (unsigned int)c[b + 1] : 0u;
-        const unsigned long long f2 = b + 2 < n ? (unsigned int)c[b + 2] : 0u;
-        w[i] = f0 | (f1 << 21) | (f2 << 42);
+        const unsigned int f0 = (unsigned int)c[b];
+        const unsigned int f1 = b + 1 < n ? (unsigned int)c[b + 1] : 0u;
+        const unsigned int f2 = b + 2 < n ? (unsigned int)c[b + 2] : 0u;
+        over = over || f0 >= limit || f1 >= limit || f2 >= limit;        // negative counts are huge as unsigned
+        w[i] = (unsigned long long)(f0 & 0x1fffffu) | ((unsigned long long)(f1 & 0x1fffffu) << 21) |
+               ((unsigned long long)(f2 & 0x1fffffu) << 42);
     }
+    if (overflow && __ballot(over) != 0ull && (threadIdx.x & 63) == 0) atomicOr(overflow, 1u);
 }
 __global__ void __launch_bounds__(256)
 k_unpack3x21(const unsigned long long *__restrict__ w, long n, long nw, int32_t *__restrict__ c) {
@@ -464,16 +470,18 @@ k_unpack3x21(const unsigned long long *__restrict__ w, long n, long nw, int32_t 
 }  // namespace
 }  // namespace vbq
 
-extern "C" int vbq_pack_counts_3x21(const int32_t *d_counts, int64_t n, int64_t *d_words, void *stream) {
+extern "C" int vbq_pack_counts_3x21(const int32_t *d_counts, int64_t n, int64_t *d_words, int32_t n_ranks,
+                                    uint32_t *d_overflow, void *stream) {
     using namespace vbq;
     VBQ_REQUIRE(n >= 0, VBQ_ERR_INVALID_ARGUMENT, "vbq_pack_counts_3x21: n < 0");
+    VBQ_REQUIRE(n_ranks >= 1 && n_ranks <= (1 << 20), VBQ_ERR_INVALID_ARGUMENT, "vbq_pack_counts_3x21: n_ranks=%d", n_ranks);
     if (n == 0) return VBQ_OK;
     VBQ_REQUIRE(d_counts && d_words, VBQ_ERR_INVALID_ARGUMENT, "vbq_pack_counts_3x21: null pointer");
     const int64_t nw = (n + 2) / 3;
     int64_t gx = (nw + 255) / 256;
     if (gx > 8192) gx = 8192;
     hipLaunchKernelGGL(k_pack3x21, dim3((unsigned)gx), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), d_counts, (long)n, (long)nw,
-                       reinterpret_cast<unsigned long long *>(d_words));
+                       reinterpret_cast<unsigned long long *>(d_words), (unsigned int)((1u << 21) / (unsigned)n_ranks), d_overflow);
     VBQ_CHECK_LAUNCH("pack_counts");
     return VBQ_OK;
 }
@@ -489,6 +497,31 @@ extern "C" int vbq_unpack_counts_3x21(const int64_t *d_words, int64_t n, int32_t
     hipLaunchKernelGGL(k_unpack3x21, dim3((unsigned)gx), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        reinterpret_cast<const unsigned long long *>(d_words), (long)n, (long)nw, d_counts);
     VBQ_CHECK_LAUNCH("unpack_counts");
+    return VBQ_OK;
+}
+
+namespace vbq {
+namespace {
+__global__ void __launch_bounds__(256)
+k_index_max(const uint16_t *__restrict__ idx, long n, unsigned int *__restrict__ out) {
+    unsigned int m = 0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) m = max(m, (unsigned int)idx[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned int)__shfl_down(m, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, m);
+}
+}  // namespace
+}  // namespace vbq
+
+extern "C" int vbq_index_max_u16(const uint16_t *d_idx, int64_t n, uint32_t *d_max, void *stream) {
+    using namespace vbq;
+    VBQ_REQUIRE(n >= 0, VBQ_ERR_INVALID_ARGUMENT, "vbq_index_max_u16: n < 0");
+    if (n == 0) return VBQ_OK;
+    VBQ_REQUIRE(d_idx && d_max, VBQ_ERR_INVALID_ARGUMENT, "vbq_index_max_u16: null pointer");
+    int64_t gx = (n + 255) / 256;
+    if (gx > 4096) gx = 4096;
+    hipLaunchKernelGGL(k_index_max, dim3((unsigned)gx), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), d_idx, (long)n, d_max);
+    VBQ_CHECK_LAUNCH("index_max");
     return VBQ_OK;
 }
 

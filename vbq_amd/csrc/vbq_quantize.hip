@@ -135,9 +135,12 @@ struct LambdaChunk {
     double lam[kMaxLambdaChunk];
 };
 
+// *odd (u32 in the workspace, zeroed per call) is raised when a caller-supplied length table yields a penalty
+// outside {0} U [2^-39, 2^70]: the fast kernel's tie certificate assumes that range, so it then sends every
+// solve through its literal scan (same answers, slower) instead of trusting a precondition it cannot see.
 template <typename T>
 __global__ void k_prepare_penalties(LambdaChunk lc, int L, int C, int N1, const float *__restrict__ level_len,
-                                    T *__restrict__ pen) {
+                                    T *__restrict__ pen, unsigned int *__restrict__ odd) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int total = L * C * N1;
     if (i >= total) return;
@@ -146,7 +149,9 @@ __global__ void k_prepare_penalties(LambdaChunk lc, int L, int C, int N1, const 
     if (sizeof(T) == 4) {
         const float lam = (float)lc.lam[l];
         const float len = level_len ? level_len[i] : (float)n;
-        pen[i] = (T)__fmul_rn(lam, len);
+        const float p = __fmul_rn(lam, len);
+        pen[i] = (T)p;
+        if (level_len && !(p == 0.0f || (p >= 1.8189894e-12f && p <= 1.1805916e21f))) atomicOr(odd, 1u);
     } else {
         const double len = level_len ? (double)level_len[i] : (double)n;
         pen[i] = (T)__dmul_rn(lc.lam[l], len);
@@ -332,6 +337,14 @@ int launch_quantize(const float *mu, const float *sg, int64_t n_rows, int32_t n_
     constexpr int N1 = N + 1;
     const int64_t E = n_rows * (int64_t)n_ch;
     PenT *pen = reinterpret_cast<PenT *>(ws);
+    // the last 64 bytes of the workspace hold the "odd penalties" flag (see k_prepare_penalties)
+    const int Lmax = L < kMaxLambdaChunk ? L : kMaxLambdaChunk;
+    unsigned int *odd = reinterpret_cast<unsigned int *>(reinterpret_cast<char *>(ws) +
+                                                         (size_t)Lmax * n_ch * N1 * sizeof(double) + 192);
+    if (hipMemsetAsync(odd, 0, sizeof(unsigned int), st) != hipSuccess) {
+        set_error("vbq_quantize_f32: hipMemsetAsync failed");
+        return VBQ_ERR_LAUNCH;
+    }
     const bool bc_to_cb = layout == VBQ_LAYOUT_BC_TO_CB && n_ch > 1;
     const bool flat = (n_ch == 1) || (layout == VBQ_LAYOUT_CB) || bc_to_cb;
 
@@ -342,7 +355,7 @@ int launch_quantize(const float *mu, const float *sg, int64_t n_rows, int32_t n_
         const int total = Lc * n_ch * N1;
         const float *len_c = level_len ? level_len + (int64_t)l0 * n_ch * N1 : nullptr;
         hipLaunchKernelGGL((k_prepare_penalties<PenT>), dim3((total + 255) / 256), dim3(256), 0, st, lc, Lc,
-                           (int)n_ch, N1, len_c, pen);
+                           (int)n_ch, N1, len_c, pen, odd);
         VBQ_CHECK_LAUNCH("prepare_penalties");
 
         uint16_t *oi = out_idx + (int64_t)l0 * E;
@@ -367,7 +380,7 @@ int launch_quantize(const float *mu, const float *sg, int64_t n_rows, int32_t n_
             if constexpr (sizeof(PenT) == 4) {
                 if (fast_ok) {
                     const int r = launch_quant_fast<N>(mu, sg, n_per_ch, n_ch, table, pen, len_c, Lc, oi, oz, ob, E,
-                                                       vec_ok | (bc_to_cb ? 2 : 0), st);
+                                                       vec_ok | (bc_to_cb ? 2 : 0), odd, st);
                     if (r != VBQ_OK) return r;
                     continue;
                 }
@@ -389,15 +402,13 @@ int launch_quantize(const float *mu, const float *sg, int64_t n_rows, int32_t n_
             constexpr int PS = (N1 + 3) & ~3;
             const size_t lds = sizeof(float) * kTileChannels * (T + 2) + 16 +
                                (sizeof(PenT) == 4 ? sizeof(PenT) * (size_t)kMaxLambdaChunk * kTileChannels * PS : 0);
-            static bool attr_set = false;
-            if (!attr_set) {
+            {   // per device and cheap: set on every call (a process may drive several GPUs)
                 hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_quant_tiled<N, PenT>),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 if (e != hipSuccess) {
                     set_error("hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
                     return VBQ_ERR_LAUNCH;
                 }
-                attr_set = true;
             }
             const int groups = (n_ch + kTileChannels - 1) / kTileChannels;
             int64_t iters = (n_rows + kRowsPerIter - 1) / kRowsPerIter;

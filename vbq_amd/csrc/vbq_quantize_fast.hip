@@ -149,13 +149,14 @@ __global__ void __launch_bounds__(kFastThreads, VBQ_FAST_WAVES)
 k_quant_fast(const float *__restrict__ mu, const float *__restrict__ sg, long n_per_ch, int C,
              const float *__restrict__ table, const float *__restrict__ pen, const float *__restrict__ len,
              int L, uint16_t *__restrict__ out_idx, float *__restrict__ out_zhat,
-             float *__restrict__ out_bits, long E, int vec_ok, int dbg) {
+             float *__restrict__ out_bits, long E, int vec_ok, int dbg, const unsigned int *__restrict__ odd_pen) {
     constexpr int T = table_size(N);
     constexpr int N1 = N + 1;
     constexpr int NE = kFastNE;
     // dbg (tests only, VBQ_FAST_DEBUG): 1 = send every solve through the literal scan,
     // 2 = never flag (shows that the flags are what keeps the fast path exact)
-    const bool force_slow = dbg == 1, never_flag = dbg == 2;
+    // *odd_pen != 0: a caller-supplied length table left the range the tie certificate assumes -> literal scan
+    const bool force_slow = dbg == 1 || *odd_pen != 0u, never_flag = dbg == 2;
     constexpr int PS = (N1 + 3) & ~3;                 // penalty row, padded to whole 16-byte LDS reads
     __shared__ float tb[T + 1];
     __shared__ uint32_t scratch[N1 * NE * kFastThreads];
@@ -366,7 +367,7 @@ k_quant_fast(const float *__restrict__ mu, const float *__restrict__ sg, long n_
 template <int N>
 int launch_quant_fast(const float *mu, const float *sg, int64_t n_per_ch, int32_t n_ch, const float *table,
                       const float *pen, const float *len, int32_t L, uint16_t *out_idx, float *out_zhat,
-                      float *out_bits, int64_t E, int vec_ok, hipStream_t st) {
+                      float *out_bits, int64_t E, int vec_ok, const unsigned int *odd_pen, hipStream_t st) {
     const int64_t nquads = (n_per_ch + kFastNE - 1) / kFastNE;
     int64_t gx = (nquads + kFastThreads - 1) / kFastThreads;
     // 3 (NE=4: 53 KB LDS each) / 5 (NE=2) workgroups per CU fit; keep every channel's share balanced
@@ -388,31 +389,31 @@ int launch_quant_fast(const float *mu, const float *sg, int64_t n_per_ch, int32_
     static const int dbg = [] { const char *e = getenv("VBQ_FAST_DEBUG"); return e ? atoi(e) : 0; }();
     if (out_zhat || out_bits)
         hipLaunchKernelGGL((k_quant_fast<N, true>), grid, block, 0, st, mu, sg, (long)n_per_ch, (int)n_ch, table, pen,
-                           len, (int)L, out_idx, out_zhat, out_bits, (long)E, vec_ok, dbg);
+                           len, (int)L, out_idx, out_zhat, out_bits, (long)E, vec_ok, dbg, odd_pen);
     else
         hipLaunchKernelGGL((k_quant_fast<N, false>), grid, block, 0, st, mu, sg, (long)n_per_ch, (int)n_ch, table, pen,
-                           len, (int)L, out_idx, out_zhat, out_bits, (long)E, vec_ok, dbg);
+                           len, (int)L, out_idx, out_zhat, out_bits, (long)E, vec_ok, dbg, odd_pen);
     VBQ_CHECK_LAUNCH("quant_fast");
     return VBQ_OK;
 }
 
 template int launch_quant_fast<10>(const float *, const float *, int64_t, int32_t, const float *, const float *,
-                                   const float *, int32_t, uint16_t *, float *, float *, int64_t, int, hipStream_t);
+                                   const float *, int32_t, uint16_t *, float *, float *, int64_t, int, const unsigned int *, hipStream_t);
 template int launch_quant_fast<12>(const float *, const float *, int64_t, int32_t, const float *, const float *,
-                                  const float *, int32_t, uint16_t *, float *, float *, int64_t, int, hipStream_t);
+                                  const float *, int32_t, uint16_t *, float *, float *, int64_t, int, const unsigned int *, hipStream_t);
 template int launch_quant_fast<11>(const float *, const float *, int64_t, int32_t, const float *, const float *,
-                                  const float *, int32_t, uint16_t *, float *, float *, int64_t, int, hipStream_t);
+                                  const float *, int32_t, uint16_t *, float *, float *, int64_t, int, const unsigned int *, hipStream_t);
 template int launch_quant_fast<8>(const float *, const float *, int64_t, int32_t, const float *, const float *,
-                                  const float *, int32_t, uint16_t *, float *, float *, int64_t, int, hipStream_t);
+                                  const float *, int32_t, uint16_t *, float *, float *, int64_t, int, const unsigned int *, hipStream_t);
 template int launch_quant_fast<9>(const float *, const float *, int64_t, int32_t, const float *, const float *,
-                                  const float *, int32_t, uint16_t *, float *, float *, int64_t, int, hipStream_t);
+                                  const float *, int32_t, uint16_t *, float *, float *, int64_t, int, const unsigned int *, hipStream_t);
 template int launch_quant_fast<7>(const float *, const float *, int64_t, int32_t, const float *, const float *,
-                                  const float *, int32_t, uint16_t *, float *, float *, int64_t, int, hipStream_t);
+                                  const float *, int32_t, uint16_t *, float *, float *, int64_t, int, const unsigned int *, hipStream_t);
 template int launch_quant_fast<5>(const float *, const float *, int64_t, int32_t, const float *, const float *,
-                                  const float *, int32_t, uint16_t *, float *, float *, int64_t, int, hipStream_t);
+                                  const float *, int32_t, uint16_t *, float *, float *, int64_t, int, const unsigned int *, hipStream_t);
 template int launch_quant_fast<6>(const float *, const float *, int64_t, int32_t, const float *, const float *,
-                                  const float *, int32_t, uint16_t *, float *, float *, int64_t, int, hipStream_t);
+                                  const float *, int32_t, uint16_t *, float *, float *, int64_t, int, const unsigned int *, hipStream_t);
 template int launch_quant_fast<4>(const float *, const float *, int64_t, int32_t, const float *, const float *,
-                                  const float *, int32_t, uint16_t *, float *, float *, int64_t, int, hipStream_t);
+                                  const float *, int32_t, uint16_t *, float *, float *, int64_t, int, const unsigned int *, hipStream_t);
 
 }  // namespace vbq

@@ -63,9 +63,13 @@ k_rans_encode(const uint16_t *__restrict__ idx, long n, int T, int seg, int nseg
     sizes[s * nseg + g] = (uint32_t)k;
 }
 
+// Untrusted input: the segment sizes and words may come from a damaged or foreign file.  Every read is kept
+// inside the segment's (seg + 2)-word buffer and every decoded symbol below T; what is wrong is reported in
+// *status (bit 0: a segment size outside [2, seg + 2]; bit 1: a segment ran out of words; bit 2: words left
+// over or a final state other than the encoder's start state; bit 3: a frequency row that does not sum to 2^15).
 __global__ void __launch_bounds__(kRansThreads)
 k_rans_decode(const uint16_t *__restrict__ words, const uint32_t *__restrict__ sizes, long n, int T, int seg, int nseg,
-              const uint16_t *__restrict__ freq, uint16_t *__restrict__ idx) {
+              const uint16_t *__restrict__ freq, uint16_t *__restrict__ idx, uint32_t *__restrict__ status) {
     __shared__ uint16_t f_l[2048];
     __shared__ uint32_t c_l[2049];
     // start[b] = the symbol whose slot range contains slot 16 b: the search for a slot begins there and walks
@@ -88,18 +92,33 @@ k_rans_decode(const uint16_t *__restrict__ words, const uint32_t *__restrict__ s
     const long a = (long)g * seg;
     const long b = a + seg < n ? a + seg : n;
     const uint16_t *in = words + (s * nseg + g) * (long)(seg + 2);
-    int k = (int)sizes[s * nseg + g];
+    uint16_t *dst = idx + s * n;
+    unsigned bad = c_l[T] == (1u << kPB) ? 0u : 8u;
+    const unsigned k0 = sizes[s * nseg + g];
+    if (k0 < 2u || k0 > (unsigned)seg + 2u) bad |= 1u;
+    if (bad) {
+        for (long i = a; i < b; ++i) dst[i] = 0;
+        if (status) atomicOr(status, bad);
+        return;
+    }
+    int k = (int)k0;
     unsigned x = ((unsigned)in[k - 1] << 16) | in[k - 2];
     k -= 2;
-    uint16_t *dst = idx + s * n;
-    for (long i = a; i < b; ++i) {
+    long i = a;
+    for (; i < b; ++i) {
         const unsigned slot = x & ((1u << kPB) - 1u);
         int lo = start[slot >> 4];                               // last symbol with cum <= slot
-        while (c_l[lo + 1] <= slot) ++lo;                        // c_l[T] = 2^15 > slot ends the walk
+        while (c_l[lo + 1] <= slot) ++lo;                        // c_l[T] = 2^15 > slot ends the walk below T
         dst[i] = (uint16_t)lo;
         x = f_l[lo] * (x >> kPB) + slot - c_l[lo];
-        if (x < kRansL) x = (x << 16) | in[--k];
+        if (x < kRansL) {
+            if (k == 0) { bad |= 2u; ++i; break; }               // a valid stream never renormalises past its first word
+            x = (x << 16) | in[--k];
+        }
     }
+    for (; i < b; ++i) dst[i] = 0;
+    if (!bad && (k != 0 || x != kRansL)) bad |= 4u;              // the encoder started from kRansL with no words written
+    if (bad && status) atomicOr(status, bad);
 }
 
 }  // namespace
@@ -122,7 +141,8 @@ extern "C" int vbq_rans_encode_u16(const uint16_t *d_idx, int64_t n_streams, int
 }
 
 extern "C" int vbq_rans_decode_u16(const uint16_t *d_words, const uint32_t *d_sizes, int64_t n_streams, int64_t n,
-                                   int32_t N, int32_t seg, const uint16_t *d_freq, uint16_t *d_idx, void *stream) {
+                                   int32_t N, int32_t seg, const uint16_t *d_freq, uint16_t *d_idx, uint32_t *d_status,
+                                   void *stream) {
     using namespace vbq;
     VBQ_REQUIRE(n_streams >= 0 && n >= 0 && N >= 1 && N <= 10 && seg >= 1 && seg <= 65533 && n_streams <= 65535,
                 VBQ_ERR_INVALID_ARGUMENT, "vbq_rans_decode_u16: bad sizes n_streams=%lld n=%lld N=%d seg=%d",
@@ -132,7 +152,7 @@ extern "C" int vbq_rans_decode_u16(const uint16_t *d_words, const uint32_t *d_si
     const int64_t nseg = (n + seg - 1) / seg;
     hipLaunchKernelGGL(k_rans_decode, dim3((unsigned)((nseg + kRansThreads - 1) / kRansThreads), (unsigned)n_streams),
                        dim3(kRansThreads), 0, reinterpret_cast<hipStream_t>(stream), d_words, d_sizes, (long)n, table_size(N),
-                       (int)seg, (int)nseg, d_freq, d_idx);
+                       (int)seg, (int)nseg, d_freq, d_idx, d_status);
     VBQ_CHECK_LAUNCH("rans_decode");
     return VBQ_OK;
 }

@@ -81,33 +81,57 @@ PACKED_FIELD_LIMIT = 1 << 21
 class CountsAllReduce:
     """SUM all-reduce of an int32 histogram [L, C, T] with fewer bytes on the wire.
 
-    While every global count is below 2^21 (global rows per channel < 2 097 152) three counters travel in one
-    int64 word (vbq_pack_counts_3x21): the SUM of the words is the field-wise sum, 2.67 instead of 4 bytes per
-    bin -- the difference between a communication-bound and a compute-bound step on two GPUs joined by a single
-    xGMI link.  Otherwise the int32 tensor is reduced as it is.  `start()` is asynchronous (the collective
-    overlaps later kernels); `wait()` leaves the global counts in the tensor given to `start()`.
+    While every global count is below 2^21 three counters travel in one int64 word (vbq_pack_counts_3x21): the SUM
+    of the words is the field-wise sum, 2.67 instead of 4 bytes per bin -- the difference between a communication-
+    bound and a compute-bound step on two GPUs joined by a single xGMI link.  Otherwise the int32 tensor is reduced
+    as it is.  `start()` is asynchronous (the collective overlaps later kernels); `wait()` leaves the global counts
+    in the tensor given to `start()`.
+
+    The packed path is chosen from the caller's `max_global_count` (an upper bound of any global bin, e.g. the
+    global number of rows per channel) and GUARDED on the device: the pack kernel raises a flag when a local count
+    reaches 2^21 / world, the flag travels in a spare word of the same all-reduce (so every rank sees the same
+    answer), and `check()` -- one device-to-host read, call it outside the timed loop, or `wait(check=True)` --
+    raises VBQError when any rank flagged: the sums of that step cannot be trusted then (use packed=False).
     """
 
-    def __init__(self, numel: int, device, max_global_count: int, group=None):
+    def __init__(self, numel: int, device, max_global_count: int, group=None, packed: Optional[bool] = None):
         self.group = group
-        self.packed = max_global_count < PACKED_FIELD_LIMIT and device.type == "cuda"
-        self.words = torch.empty((numel + 2) // 3, dtype=torch.int64, device=device) if self.packed else None
+        fits = max_global_count < PACKED_FIELD_LIMIT and device.type == "cuda"
+        self.packed = fits if packed is None else (bool(packed) and device.type == "cuda")
+        self.nw = (numel + 2) // 3
+        # word nw carries the overflow flags of all ranks (their sum)
+        self.words = torch.zeros(self.nw + 1, dtype=torch.int64, device=device) if self.packed else None
         self._work = None
         self._counts = None
 
+    @staticmethod
+    def _require_group(group):
+        if not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError("CountsAllReduce needs an initialised torch.distributed process group "
+                               "(vbq_amd.dist.init_from_env())")
+        return dist.get_world_size(group)
+
+    def payload_bytes(self, counts: torch.Tensor) -> int:
+        return self.words.numel() * 8 if self.packed else counts.numel() * counts.element_size()
+
     def start(self, counts: torch.Tensor):
         from . import _lib, ops
+        world = self._require_group(self.group)
         assert counts.dtype == torch.int32 and counts.is_contiguous()
         self._counts = counts
         if self.packed:
-            _lib.check(_lib.lib().vbq_pack_counts_3x21(ops._ptr(counts), counts.numel(), ops._ptr(self.words), ops._stream(counts)),
-                       "vbq_pack_counts_3x21")
+            assert (counts.numel() + 2) // 3 == self.nw
+            self.words[self.nw:].zero_()
+            flag_ptr = self.words.data_ptr() + 8 * self.nw
+            import ctypes as C
+            _lib.check(_lib.lib().vbq_pack_counts_3x21(ops._ptr(counts), counts.numel(), ops._ptr(self.words), world,
+                                                       C.c_void_p(flag_ptr), ops._stream(counts)), "vbq_pack_counts_3x21")
             self._work = dist.all_reduce(self.words, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         else:
             self._work = dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         return self
 
-    def wait(self):
+    def wait(self, check: bool = False):
         from . import _lib, ops
         if self._work is None:
             return
@@ -117,3 +141,13 @@ class CountsAllReduce:
             _lib.check(_lib.lib().vbq_unpack_counts_3x21(ops._ptr(self.words), c.numel(), ops._ptr(c), ops._stream(c)),
                        "vbq_unpack_counts_3x21")
         self._work = None
+        if check:
+            self.check()
+
+    def check(self):
+        """Raise if, in the most recent packed reduce, any rank held a count that could have carried into the
+        neighbouring field (synchronises: one 8-byte read)."""
+        from ._lib import VBQError
+        if self.packed and int(self.words[self.nw].item()) != 0:
+            raise VBQError("packed 3x21-bit histogram all-reduce overflowed: a local count reached 2^21 / world_size; "
+                           "the reduced counts of that step are invalid -- use CountsAllReduce(..., packed=False)")

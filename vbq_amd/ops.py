@@ -156,6 +156,8 @@ def histogram(idx: torch.Tensor, n_ch: int, *, N: int = 10, layout="bc", out: Op
     else:
         if out.dtype not in (torch.int64, torch.int32):
             raise ValueError("out must be int64 or int32")
+        if not out.is_contiguous():
+            raise ValueError("out must be contiguous (counts are accumulated in place)")
         out = _dev(out, out.dtype, "out")
         if tuple(out.shape) != (L, n_ch, T):
             raise ValueError(f"out shape {tuple(out.shape)} != {(L, n_ch, T)}")
@@ -164,6 +166,15 @@ def histogram(idx: torch.Tensor, n_ch: int, *, N: int = 10, layout="bc", out: Op
                (h.vbq_histogram_u16_i32, "vbq_histogram_u16_i32")
     check(fn(_ptr(idx), rows, n_ch, layout, L, N, _ptr(out), _stream(idx)), name)
     return out
+
+
+def index_max(idx: torch.Tensor) -> int:
+    """vbq_index_max_u16: the largest index of a u16 array (synchronises).  For indices of foreign origin: K2 and
+    gather are memory-safe for anything, but only indices < T are meaningful."""
+    idx = _dev(idx, torch.uint16, "idx")
+    m = torch.zeros(1, dtype=torch.uint32, device=idx.device)
+    check(_lib.lib().vbq_index_max_u16(_ptr(idx), idx.numel(), _ptr(m), _stream(idx)), "vbq_index_max_u16")
+    return int(m.cpu().item())
 
 
 def moments(x: torch.Tensor, *, layout="bc", out: Optional[torch.Tensor] = None):
