@@ -115,6 +115,45 @@ int vbq_quantize_f32(const float *d_mu, const float *d_sigma, int64_t n_rows, in
                      uint16_t *d_out_idx, float *d_out_zhat, float *d_out_bits,
                      void *d_workspace, size_t workspace_bytes, void *stream);
 
+/* The same solve on rows [row_begin, row_end) of the full arrays (pointers, n_rows and output addressing are those
+ * of the whole tensor): lets the caller cut one pass into chunks and run K2 on chunk j (another stream) while K1
+ * works on chunk j + 1.  workgroups_per_cu = 0: default grid; 1..5: a persistent grid of that many workgroups per
+ * CU (4 leaves the LDS and the wave slots a concurrently running K2 needs).  For planes (VBQ_LAYOUT_CB) the
+ * vector path wants row_begin % 8 == 0. */
+int vbq_quantize_rows_f32(const float *d_mu, const float *d_sigma, int64_t n_rows, int32_t n_ch,
+                          int32_t layout, const float *d_table_lm, const float *d_level_len,
+                          const double *h_lambdas, int32_t n_lambda, int32_t N, int32_t mode,
+                          uint16_t *d_out_idx, float *d_out_zhat, float *d_out_bits,
+                          void *d_workspace, size_t workspace_bytes, int64_t row_begin, int64_t row_end,
+                          int32_t workgroups_per_cu, void *stream);
+
+/* ----------------------------------------------------------------------------------
+ * K1h  Solve + bit-length histogram in one kernel, nothing written per element.  Replaces the FIRST pass of
+ *      ChannelwisePriorCDFQuantizer.build_entropy_models (quantizer.py:96-105): compress_batch_channel_latents
+ *      followed by np.bincount(raw_num_bits[:, c], minlength=N+1) per lambda and channel -- which needs the bit
+ *      level of every winner and nothing else.  Same arithmetic and tie rules as vbq_quantize_f32 (VBQ_MODE_F32).
+ *   d_level_counts  int64 [n_lambda][n_ch][N+1], ADDED to (zero it first).
+ *   layout          VBQ_LAYOUT_CB, VBQ_LAYOUT_BC_TO_CB, or any layout with n_ch == 1.
+ *   Returns VBQ_ERR_UNSUPPORTED for lambdas outside [1.9e-12, 1.8e19] (use vbq_quantize_f32 + vbq_histogram_u16).
+ * ---------------------------------------------------------------------------------- */
+int vbq_level_counts_f32(const float *d_mu, const float *d_sigma, int64_t n_rows, int32_t n_ch,
+                         int32_t layout, const float *d_table_lm, const float *d_level_len,
+                         const double *h_lambdas, int32_t n_lambda, int32_t N, int64_t *d_level_counts,
+                         void *d_workspace, size_t workspace_bytes, void *stream);
+
+/* Code lengths from counts through a table: out[i] = (level_period ? i % level_period : 0) + lut[counts[i]].
+ * Replaces the float32 arithmetic of quantizer.py:105-110 / 141-146 (counts + n -> / sum -> -log2) when the caller
+ * can tabulate it: with B elements per (lambda, channel) row and add-n smoothing, every row's sum is the same
+ * exact integer B + K n (< 2^24), so -log2(f32(k + n) / f32(B + K n)) is a function of the count k alone; the
+ * caller builds lut[0..B] on the HOST with the reference's own NumPy operations (bit-identical by construction)
+ * and the table lookup keeps the whole alternation on the device.  level_period = N + 1 adds the bit level n to
+ * every entry (the "n + overhead" of quantizer.py:171-175, one f32 add).  Counts outside [0, lut_n) clamp.
+ *   d_counts      int64 (counts_are_i32 = 0) or int32 (!= 0), n entries
+ *   d_out_len     optional f32 [n]: level + lut[count];  d_out_model optional f32 [n]: lut[count] */
+int vbq_code_lengths_from_counts(const void *d_counts, int32_t counts_are_i32, int64_t n,
+                                 const float *d_lut, int64_t lut_n, int32_t level_period,
+                                 float *d_out_len, float *d_out_model, void *stream);
+
 /* ----------------------------------------------------------------------------------
  * K1c  Generic candidate solve.  Replaces utils.batch_quantize_indep_dims
  *      (img-compression/utils.py:363-423) for caller-built candidates, i.e. its
@@ -162,6 +201,12 @@ int vbq_histogram_u16(const uint16_t *d_idx, int64_t n_rows, int32_t n_ch, int32
  * all ranks whose histograms will be summed into this buffer) is below 2^31. */
 int vbq_histogram_u16_i32(const uint16_t *d_idx, int64_t n_rows, int32_t n_ch, int32_t layout,
                           int32_t n_lambda, int32_t N, int32_t *d_counts, void *stream);
+
+/* K2 on rows [row_begin, row_end) of the full index array (same addressing rules as vbq_quantize_rows_f32);
+ * d_counts is int32 when counts_are_i32 != 0, else int64. */
+int vbq_histogram_rows_u16(const uint16_t *d_idx, int64_t n_rows, int32_t n_ch, int32_t layout,
+                           int32_t n_lambda, int32_t N, void *d_counts, int32_t counts_are_i32,
+                           int64_t row_begin, int64_t row_end, void *stream);
 
 /* Largest index of a u16 index array (d_max: u32, device, MAX-ed into; zero it first).  K2 and the gather are
  * memory-safe for any u16 input (indices >= T are counted in a wrapped bin / read the last table entry); a

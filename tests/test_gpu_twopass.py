@@ -1,0 +1,179 @@
+"""The pieces of the two-pass entropy-model build (quantizer.py:82-150) that round 2 added, against the oracle:
+K1h (solve + bit-length histogram, no per-element output), the row-range forms of K1 / K2 that let the host overlap
+them, and the table-driven code lengths.  Counts are integers: everything is compared with array_equal."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from oracle import c_oracle as CO
+from oracle import vbq_oracle as O
+
+pytestmark = pytest.mark.gpu
+N = 10
+T = 2047
+LAM32 = list(2.0 ** np.linspace(-8, 7.5, 32))
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.fail("gpu-marked test run without a ROCm device")
+    from vbq_amd import ops as _ops
+    return _ops
+
+
+def dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a)).cuda()
+
+
+def synth(rng, rows, C):
+    scale = np.exp(rng.uniform(np.log(0.3), np.log(3.0), C))
+    orc = O.ChannelwiseOracle(C, N)
+    orc.build_code_points(O.factored_gaussian_icdf(np.zeros(C), scale))
+    mu = (scale * rng.normal(0, 1.0, (rows, C))).astype(np.float32)
+    sg = np.clip(np.exp(rng.normal(-2, 0.7, (rows, C))), 1e-4, 10).astype(np.float32)
+    return orc.all_code_points, mu, sg
+
+
+def oracle_level_counts(mu, sg, tab, lam, level_len=None):
+    """[L, C, N+1] from the C oracle's indices: np.bincount(raw_num_bits[:, c], minlength=N+1) (quantizer.py:104)."""
+    idx = CO.quantize(mu, sg, tab, lam, N=N, level_len=level_len, threads=8)          # [L, rows, C]
+    lev = O.levels_of_sorted_ranks(N)[idx]
+    L, rows, C = lev.shape
+    return np.stack([[np.bincount(lev[l, :, c], minlength=N + 1) for c in range(C)] for l in range(L)]).astype(np.int64)
+
+
+def random_level_len(rng, L, C):
+    over = rng.uniform(0.0, 9.0, (L, C, N + 1)).astype(np.float32)
+    return (np.arange(N + 1, dtype=np.float32)[None, None, :] + over).astype(np.float32)
+
+
+@pytest.mark.parametrize("rows,C", [(1, 1), (5, 1), (1021, 1), (70001, 1), (777, 2), (257, 17), (1536, 32), (4104, 5)])
+def test_level_counts_vs_oracle(ops, rows, C):
+    rng = np.random.default_rng(rows * 7 + C)
+    tab, mu, sg = synth(rng, rows, C)
+    lam = LAM32 if rows * C < 60000 else LAM32[::4]
+    for ll in (None, random_level_len(rng, len(lam), C)):
+        want = oracle_level_counts(mu, sg, tab, lam, ll)
+        lld = None if ll is None else dev(ll)
+        if C == 1:
+            got = ops.level_counts(dev(mu[:, 0]), dev(sg[:, 0]), dev(tab), lam, N=N, level_len=lld)
+        else:
+            got = ops.level_counts(dev(mu.T), dev(sg.T), dev(tab), lam, N=N, level_len=lld, layout="cb")
+            got2 = ops.level_counts(dev(mu), dev(sg), dev(tab), lam, N=N, level_len=lld, layout="bc->cb")
+            assert torch.equal(got, got2)
+        assert got.dtype == torch.int64 and tuple(got.shape) == (len(lam), C, N + 1)
+        assert np.array_equal(got.cpu().numpy(), want)
+        assert int(got.sum().item()) == rows * C * len(lam)
+    # accumulation into a caller's buffer
+    out = ops.level_counts(dev(mu.T) if C > 1 else dev(mu[:, 0]), dev(sg.T) if C > 1 else dev(sg[:, 0]), dev(tab), lam, N=N,
+                           layout="cb" if C > 1 else "bc", out=got.clone())
+    assert np.array_equal(out.cpu().numpy(), want + oracle_level_counts(mu, sg, tab, lam, None))
+
+
+def test_level_counts_ties_and_edges(ops):
+    """Inputs that force the events the fast path cannot decide by itself (exact code-point hits, exact mid-points
+    between neighbours of different levels, values outside the table, extreme sigmas): the level of the winner must
+    still be the reference's, i.e. the literal scan takes over."""
+    rng = np.random.default_rng(5)
+    tab, _, _ = synth(rng, 4, 1)
+    t = np.sort(tab[0])
+    mids = (t[:-1] + t[1:]) * np.float32(0.5)
+    mu = np.concatenate([t, mids, [t[0] - 50, t[-1] + 50, t[0], t[-1], 0.0], rng.normal(0, 1, 3000).astype(np.float32)]).astype(np.float32)
+    sg = np.concatenate([np.full(t.size + mids.size + 5, 1.0), np.exp(rng.normal(-2, 2.5, 3000))]).astype(np.float32)
+    sg[::7] = np.float32(0.99999994)                                # all-ones mantissa
+    lam = [2.0 ** k for k in range(-10, 9)] + [1.0, 3.0]
+    for ll in (None, random_level_len(rng, len(lam), 1), np.ones((len(lam), 1, N + 1), np.float32)):
+        want = oracle_level_counts(mu[:, None], sg[:, None], tab, lam, ll)
+        got = ops.level_counts(dev(mu), dev(sg), dev(tab), lam, N=N, level_len=None if ll is None else dev(ll))
+        assert np.array_equal(got.cpu().numpy(), want)
+
+
+def test_level_counts_agrees_with_quantize_plus_histogram(ops):
+    """Same counts as the two-kernel route (K1 indices -> K2 rank histogram -> sum over the ranks of a level)."""
+    from vbq_amd import entropy
+    rng = np.random.default_rng(11)
+    tab, mu, sg = synth(rng, 36864 // 8, 24)
+    mu_cb, sg_cb, tabd = dev(mu.T), dev(sg.T), dev(tab)
+    idx = ops.quantize(mu_cb, sg_cb, tabd, LAM32, N=N, layout="cb")
+    via_hist = entropy.level_counts_from_counts(ops.histogram(idx, 24, N=N, layout="cb"), N)
+    assert torch.equal(ops.level_counts(mu_cb, sg_cb, tabd, LAM32, N=N, layout="cb"), via_hist)
+
+
+def test_level_counts_rejects_what_it_does_not_serve(ops):
+    from vbq_amd._lib import VBQError
+    rng = np.random.default_rng(2)
+    tab, mu, sg = synth(rng, 64, 3)
+    with pytest.raises(VBQError, match="channel-last"):
+        ops.level_counts(dev(mu), dev(sg), dev(tab), [1.0], N=N, layout="bc")
+    with pytest.raises(VBQError, match="fast f32 kernel"):
+        ops.level_counts(dev(mu.T), dev(sg.T), dev(tab), [1e-30], N=N, layout="cb")
+
+
+@pytest.mark.parametrize("rows,C,cuts", [(4096, 6, (0, 1024, 1032, 4096)), (10007, 1, (0, 8, 5000, 10007)),
+                                         (1000, 3, (0, 3, 501, 1000)), (2048, 1, (0, 0, 2048, 2048))])
+def test_row_ranges_equal_whole(ops, rows, C, cuts):
+    """vbq_quantize_rows_f32 / vbq_histogram_rows_u16: chunks (aligned or not, empty ones included) reproduce the
+    one-launch result bit for bit, with and without the persistent 4-workgroups-per-CU grid."""
+    rng = np.random.default_rng(rows + C)
+    tab, mu, sg = synth(rng, rows, C)
+    lam = LAM32[::3]
+    ll = dev(random_level_len(rng, len(lam), C))
+    m, s = (dev(mu.T), dev(sg.T)) if C > 1 else (dev(mu[:, 0]), dev(sg[:, 0]))
+    layout = "cb" if C > 1 else "bc"
+    whole, zw, bw = ops.quantize(m, s, dev(tab), lam, N=N, level_len=ll, layout=layout, want_zhat=True, want_bits=True)
+    cw = ops.histogram(whole, C, N=N, layout=layout)
+    for wg in (0, 4):
+        idx = torch.full_like(whole, 0xffff)
+        zh, bt = torch.full_like(zw, -1.0), torch.full_like(bw, -1.0)
+        cnt = torch.zeros_like(cw)
+        cnt32 = torch.zeros(cw.shape, dtype=torch.int32, device="cuda")
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            ops.quantize(m, s, dev(tab), lam, N=N, level_len=ll, layout=layout, out_idx=idx, out_zhat=zh, out_bits=bt,
+                         rows=(a, b), workgroups_per_cu=wg)
+            ops.histogram(idx, C, N=N, layout=layout, out=cnt, rows=(a, b))
+            ops.histogram(idx, C, N=N, layout=layout, out=cnt32, rows=(a, b))
+        assert torch.equal(idx.view(torch.int16), whole.view(torch.int16))
+        assert torch.equal(zh, zw) and torch.equal(bt, bw)
+        assert torch.equal(cnt, cw) and torch.equal(cnt32.to(torch.int64), cw)
+    from vbq_amd._lib import VBQError
+    with pytest.raises(VBQError, match="row range"):
+        ops.quantize(m, s, dev(tab), lam, N=N, level_len=ll, layout=layout, rows=(5, rows + 1))
+    with pytest.raises(VBQError, match="row range"):
+        ops.histogram(whole, C, N=N, layout=layout, rows=(7, 3))
+
+
+def test_row_ranges_channel_last(ops):
+    rng = np.random.default_rng(77)
+    tab, mu, sg = synth(rng, 900, 20)
+    lam = LAM32[::6]
+    whole = ops.quantize(dev(mu), dev(sg), dev(tab), lam, N=N)                      # [L, rows, C], tiled kernel
+    idx = torch.zeros_like(whole)
+    cnt = torch.zeros((len(lam), 20, T), dtype=torch.int64, device="cuda")
+    for a, b in ((0, 130), (130, 131), (131, 900)):
+        ops.quantize(dev(mu), dev(sg), dev(tab), lam, N=N, out_idx=idx, rows=(a, b))
+        ops.histogram(idx, 20, N=N, out=cnt, rows=(a, b))
+    assert torch.equal(idx.view(torch.int16), whole.view(torch.int16))
+    assert torch.equal(cnt, ops.histogram(whole, 20, N=N))
+
+
+def test_code_lengths_from_counts_match_numpy(ops):
+    """The table-driven form of quantizer.py:105-110 / 141-146: lut built on the host with the reference's NumPy
+    float32 operations, looked up on the device, equals those operations applied to the counts directly."""
+    from vbq_amd import entropy
+    rng = np.random.default_rng(3)
+    B, C, L, smooth = 36864, 7, 5, 1
+    for K, period in ((N + 1, N + 1), (T, 0)):
+        p = rng.dirichlet(np.full(K, 0.05), size=(L, C))
+        counts = np.stack([[rng.multinomial(B, p[l, c]) for c in range(C)] for l in range(L)]).astype(np.int64)
+        want_model = entropy.neg_log2_freq(counts, smooth)                              # [L, C, K] f32, NumPy
+        lut = entropy.neg_log2_lut(B, K, smooth)
+        assert lut is not None and lut.dtype == np.float32 and lut.shape == (B + 1,)
+        for dt in (torch.int64, torch.int32):
+            ln, model = ops.code_lengths_from_counts(dev(counts).to(dt), dev(lut), level_period=period, want_model=True)
+            assert np.array_equal(model.cpu().numpy(), want_model)
+            lv = np.arange(K, dtype=np.float32) if period else np.zeros(K, np.float32)
+            assert np.array_equal(ln.cpu().numpy(), (lv + want_model).astype(np.float32))
+    assert entropy.neg_log2_lut(1 << 24, T, 1) is None                                  # sums no longer exact in f32
+    assert entropy.neg_log2_lut(1000, T, 0.5) is None                                   # non-integer smoothing

@@ -27,6 +27,16 @@ SIGNATURES = {
     "vbq_quantize_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                    C.POINTER(C.c_double), C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "vbq_quantize_rows_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                        C.POINTER(C.c_double), C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_size_t, C.c_int64, C.c_int64, C.c_int32, C.c_void_p]),
+    "vbq_level_counts_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                       C.POINTER(C.c_double), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t,
+                                       C.c_void_p]),
+    "vbq_code_lengths_from_counts": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_int64, C.c_int32,
+                                               C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vbq_histogram_rows_u16": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
+                                         C.c_int32, C.c_int64, C.c_int64, C.c_void_p]),
     "vbq_quantize_notebook_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_double),
                                             C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vbq_histogram_u16": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,

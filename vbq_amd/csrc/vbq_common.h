@@ -42,10 +42,21 @@ __device__ __forceinline__ float neg_half_sq_err(float P, float mu, float sigma)
     return __fmul_rn(-0.5f, q);
 }
 
-// vbq_quantize_fast.hip
+// Bit depths the kernels are instantiated for.  The reference uses N = 10 only (post_process.py:117); the others are
+// an extension that costs build time: -DVBQ_ONLY_N10 builds the reference's depth alone.
+#ifdef VBQ_ONLY_N10
+#define VBQ_FOR_EACH_N(X) X(10)
+#else
+#define VBQ_FOR_EACH_N(X) X(12) X(11) X(10) X(9) X(8) X(7) X(6) X(5) X(4)
+#endif
+
+// vbq_quantize_fast.hip.  Elements of channel c start at c * ch_stride (n_per_ch of them are processed); E is the
+// distance between the lambda planes of the outputs.  level_counts != NULL selects the counting mode (no element
+// output).  wg_per_cu in 1..5 makes the grid persistent at that many workgroups per CU (0: the default sizing).
 template <int N>
-int launch_quant_fast(const float *mu, const float *sg, int64_t n_per_ch, int32_t n_ch, const float *table,
+int launch_quant_fast(const float *mu, const float *sg, int64_t n_per_ch, int64_t ch_stride, int32_t n_ch, const float *table,
                       const float *pen, const float *len, int32_t L, uint16_t *out_idx, float *out_zhat,
-                      float *out_bits, int64_t E, int vec_ok, const unsigned int *odd_pen, hipStream_t st);
+                      float *out_bits, int64_t E, int vec_ok, const unsigned int *odd_pen,
+                      unsigned long long *level_counts, int wg_per_cu, hipStream_t st);
 
 }  // namespace vbq

@@ -78,14 +78,14 @@ __device__ __forceinline__ void hist_add8(unsigned int *h, const uint4 v) {
 // All indices of the workgroup belong to one channel: [l][c][n_per_ch] contiguous.
 template <int N, typename CountT>
 __global__ void __launch_bounds__(kHistThreads)
-k_hist_flat(const uint16_t *__restrict__ idx, long n_per_ch, int C, long E,
+k_hist_flat(const uint16_t *__restrict__ idx, long n_per_ch, long ch_stride, int C, long E,
             CountT *__restrict__ counts, int vec_ok) {
     constexpr int T = table_size(N);
     constexpr int kHistCopies = hist_copies(T);
     static_assert(T + 1 <= 8192, "bins are laid out for at most 8192 slots");
     __shared__ __align__(16) unsigned int h[8192];
     const int c = blockIdx.y, l = blockIdx.z;
-    const uint16_t *src = idx + (long)l * E + (long)c * n_per_ch;
+    const uint16_t *src = idx + (long)l * E + (long)c * ch_stride;
     const long noct = vec_ok ? (n_per_ch >> 3) : 0;
     const long stride = (long)gridDim.x * blockDim.x;
     long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -182,21 +182,24 @@ k_hist_tiled(const uint16_t *__restrict__ idx, long n_rows, int C, long E,
     }
 }
 
+// Rows [row_begin, row_end) of the full [L][n_rows x n_ch] index array (lambda planes E = n_rows * n_ch apart).
 template <int N, typename CountT>
 int launch_hist(const uint16_t *idx, int64_t n_rows, int32_t n_ch, int32_t layout, int32_t L,
-                CountT *counts, hipStream_t st) {
+                CountT *counts, int64_t row_begin, int64_t row_end, hipStream_t st) {
     const int64_t E = n_rows * (int64_t)n_ch;
+    const int64_t n_sub = row_end - row_begin;
     const bool flat = (n_ch == 1) || (layout == VBQ_LAYOUT_CB);
     if (flat) {
-        const int64_t n_per_ch = (n_ch == 1) ? E : n_rows;
-        const int vec_ok = (reinterpret_cast<uintptr_t>(idx) % 16 == 0) && (n_per_ch % 8 == 0 || (n_ch == 1 && L == 1)) &&
+        const uint16_t *src = idx + row_begin;
+        const int64_t n_per_ch = n_sub;
+        const int vec_ok = (reinterpret_cast<uintptr_t>(src) % 16 == 0) && (n_rows % 8 == 0 || (n_ch == 1 && L == 1)) &&
                            (E % 8 == 0 || L == 1);
         int64_t gx = (n_per_ch / 8 + kHistThreads - 1) / kHistThreads;
         int64_t cap = (int64_t)2048 / ((int64_t)n_ch * L) + 1;
         if (gx > cap) gx = cap;
         if (gx < 1) gx = 1;
         hipLaunchKernelGGL((k_hist_flat<N, CountT>), dim3((unsigned)gx, (unsigned)n_ch, (unsigned)L), dim3(kHistThreads), 0, st,
-                           idx, (long)n_per_ch, (int)n_ch, (long)E, counts, vec_ok);
+                           src, (long)n_per_ch, (long)n_rows, (int)n_ch, (long)E, counts, vec_ok);
         VBQ_CHECK_LAUNCH("hist_flat");
     } else if constexpr (N > 10) {
         set_error("histogram: N=%d is built for channel-major planes only (VBQ_LAYOUT_CB, or n_ch = 1)", N);
@@ -214,11 +217,11 @@ int launch_hist(const uint16_t *idx, int64_t n_rows, int32_t n_ch, int32_t layou
         }
         const int groups = (n_ch + kTileChannels - 1) / kTileChannels;
         int64_t gx = 512 / ((int64_t)groups * L) + 1;
-        const int64_t iters = (n_rows + 63) / 64;
+        const int64_t iters = (n_sub + 63) / 64;
         if (gx > iters) gx = iters;
         if (gx < 1) gx = 1;
         hipLaunchKernelGGL((k_hist_tiled<N, CountT>), dim3((unsigned)gx, (unsigned)groups, (unsigned)L),
-                           dim3(kHistTiledThreads), lds, st, idx, (long)n_rows, (int)n_ch, (long)E, counts);
+                           dim3(kHistTiledThreads), lds, st, idx + row_begin * n_ch, (long)n_sub, (int)n_ch, (long)E, counts);
         VBQ_CHECK_LAUNCH("hist_tiled");
     }
     return VBQ_OK;
@@ -395,30 +398,41 @@ namespace vbq {
 namespace {
 template <typename CountT>
 int histogram_entry(const char *who, const uint16_t *d_idx, int64_t n_rows, int32_t n_ch, int32_t layout,
-                    int32_t n_lambda, int32_t N, CountT *cnt, void *stream) {
+                    int32_t n_lambda, int32_t N, CountT *cnt, int64_t row_begin, int64_t row_end, void *stream) {
     VBQ_REQUIRE(n_rows >= 0 && n_ch >= 1 && n_lambda >= 1 && n_lambda <= 65535 && n_ch <= 65535,
                 VBQ_ERR_INVALID_ARGUMENT, "%s: bad sizes n_rows=%lld n_ch=%d n_lambda=%d", who, (long long)n_rows, n_ch,
                 n_lambda);
-    VBQ_REQUIRE(n_rows == 0 || (d_idx && cnt), VBQ_ERR_INVALID_ARGUMENT, "%s: null pointer argument", who);
+    VBQ_REQUIRE(0 <= row_begin && row_begin <= row_end && row_end <= n_rows, VBQ_ERR_INVALID_ARGUMENT,
+                "%s: row range [%lld, %lld) outside [0, %lld)", who, (long long)row_begin, (long long)row_end, (long long)n_rows);
+    VBQ_REQUIRE(row_begin == row_end || (d_idx && cnt), VBQ_ERR_INVALID_ARGUMENT, "%s: null pointer argument", who);
     VBQ_REQUIRE(layout == VBQ_LAYOUT_BC || layout == VBQ_LAYOUT_CB, VBQ_ERR_INVALID_ARGUMENT, "%s: unknown layout %d",
                 who, layout);
     VBQ_REQUIRE(sizeof(CountT) == 8 || n_rows <= 0x7fffffffLL, VBQ_ERR_INVALID_ARGUMENT,
                 "%s: %lld rows per channel can overflow 32-bit counters", who, (long long)n_rows);
-    if (n_rows == 0) return VBQ_OK;
+    if (row_begin == row_end) return VBQ_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#define VBQ_DISPATCH_N(NN) \
+    case NN: return launch_hist<NN, CountT>(d_idx, n_rows, n_ch, layout, n_lambda, cnt, row_begin, row_end, st);
     switch (N) {
-        case 12: return launch_hist<12, CountT>(d_idx, n_rows, n_ch, layout, n_lambda, cnt, st);
-        case 11: return launch_hist<11, CountT>(d_idx, n_rows, n_ch, layout, n_lambda, cnt, st);
-        case 10: return launch_hist<10, CountT>(d_idx, n_rows, n_ch, layout, n_lambda, cnt, st);
-        case 9: return launch_hist<9, CountT>(d_idx, n_rows, n_ch, layout, n_lambda, cnt, st);
-        case 8: return launch_hist<8, CountT>(d_idx, n_rows, n_ch, layout, n_lambda, cnt, st);
-        case 7: return launch_hist<7, CountT>(d_idx, n_rows, n_ch, layout, n_lambda, cnt, st);
-        case 6: return launch_hist<6, CountT>(d_idx, n_rows, n_ch, layout, n_lambda, cnt, st);
-        case 5: return launch_hist<5, CountT>(d_idx, n_rows, n_ch, layout, n_lambda, cnt, st);
-        case 4: return launch_hist<4, CountT>(d_idx, n_rows, n_ch, layout, n_lambda, cnt, st);
+        VBQ_FOR_EACH_N(VBQ_DISPATCH_N)
         default:
-            set_error("%s: max_bits_per_coord N=%d not built (have 4 ... 12)", who, N);
+            set_error("%s: max_bits_per_coord N=%d not built (have 4 ... 12; only 10 with VBQ_ONLY_N10)", who, N);
             return VBQ_ERR_UNSUPPORTED;
+    }
+#undef VBQ_DISPATCH_N
+}
+
+// out[i] = (period ? i % period : 0) + lut[min(counts[i], lut_n - 1)]
+template <typename CountT>
+__global__ void __launch_bounds__(256)
+k_lut_lengths(const CountT *__restrict__ counts, long n, const float *__restrict__ lut, long lut_n, int period,
+              float *__restrict__ out, float *__restrict__ out_model) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        long k = (long)counts[i];
+        k = k < 0 ? 0 : (k >= lut_n ? lut_n - 1 : k);
+        const float m = lut[k];
+        if (out_model) out_model[i] = m;
+        if (out) out[i] = period ? __fadd_rn((float)(int)(i % period), m) : m;
     }
 }
 }  // namespace
@@ -427,13 +441,46 @@ int histogram_entry(const char *who, const uint16_t *d_idx, int64_t n_rows, int3
 extern "C" int vbq_histogram_u16(const uint16_t *d_idx, int64_t n_rows, int32_t n_ch, int32_t layout,
                                  int32_t n_lambda, int32_t N, int64_t *d_counts, void *stream) {
     return vbq::histogram_entry<unsigned long long>("vbq_histogram_u16", d_idx, n_rows, n_ch, layout, n_lambda, N,
-                                                    reinterpret_cast<unsigned long long *>(d_counts), stream);
+                                                    reinterpret_cast<unsigned long long *>(d_counts), 0, n_rows, stream);
 }
 
 extern "C" int vbq_histogram_u16_i32(const uint16_t *d_idx, int64_t n_rows, int32_t n_ch, int32_t layout,
                                      int32_t n_lambda, int32_t N, int32_t *d_counts, void *stream) {
     return vbq::histogram_entry<unsigned int>("vbq_histogram_u16_i32", d_idx, n_rows, n_ch, layout, n_lambda, N,
-                                              reinterpret_cast<unsigned int *>(d_counts), stream);
+                                              reinterpret_cast<unsigned int *>(d_counts), 0, n_rows, stream);
+}
+
+extern "C" int vbq_histogram_rows_u16(const uint16_t *d_idx, int64_t n_rows, int32_t n_ch, int32_t layout,
+                                      int32_t n_lambda, int32_t N, void *d_counts, int32_t counts_are_i32,
+                                      int64_t row_begin, int64_t row_end, void *stream) {
+    if (counts_are_i32)
+        return vbq::histogram_entry<unsigned int>("vbq_histogram_rows_u16", d_idx, n_rows, n_ch, layout, n_lambda, N,
+                                                  reinterpret_cast<unsigned int *>(d_counts), row_begin, row_end, stream);
+    return vbq::histogram_entry<unsigned long long>("vbq_histogram_rows_u16", d_idx, n_rows, n_ch, layout, n_lambda, N,
+                                                    reinterpret_cast<unsigned long long *>(d_counts), row_begin, row_end, stream);
+}
+
+extern "C" int vbq_code_lengths_from_counts(const void *d_counts, int32_t counts_are_i32, int64_t n,
+                                            const float *d_lut, int64_t lut_n, int32_t level_period,
+                                            float *d_out_len, float *d_out_model, void *stream) {
+    using namespace vbq;
+    VBQ_REQUIRE(n >= 0 && lut_n >= 1 && level_period >= 0, VBQ_ERR_INVALID_ARGUMENT,
+                "vbq_code_lengths_from_counts: bad sizes n=%lld lut_n=%lld period=%d", (long long)n, (long long)lut_n, level_period);
+    if (n == 0) return VBQ_OK;
+    VBQ_REQUIRE(d_counts && d_lut && (d_out_len || d_out_model), VBQ_ERR_INVALID_ARGUMENT,
+                "vbq_code_lengths_from_counts: null pointer argument");
+    int64_t gx = (n + 255) / 256;
+    if (gx > 4096) gx = 4096;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (counts_are_i32)
+        hipLaunchKernelGGL(k_lut_lengths<int32_t>, dim3((unsigned)gx), dim3(256), 0, st, reinterpret_cast<const int32_t *>(d_counts),
+                           (long)n, d_lut, (long)lut_n, (int)level_period, d_out_len, d_out_model);
+    else
+        hipLaunchKernelGGL(k_lut_lengths<long long>, dim3((unsigned)gx), dim3(256), 0, st,
+                           reinterpret_cast<const long long *>(d_counts), (long)n, d_lut, (long)lut_n, (int)level_period, d_out_len,
+                           d_out_model);
+    VBQ_CHECK_LAUNCH("code_lengths_from_counts");
+    return VBQ_OK;
 }
 
 // ---------------------------------------------------------------------------- packed counters for the all-reduce

@@ -166,7 +166,7 @@ __global__ void k_prepare_penalties(LambdaChunk lc, int L, int C, int N1, const 
 // ------------------------------------------------------------------------------------
 template <int N, typename PenT>
 __global__ void __launch_bounds__(256)
-k_quant_flat(const float *__restrict__ mu, const float *__restrict__ sg, long n_per_ch, int C,
+k_quant_flat(const float *__restrict__ mu, const float *__restrict__ sg, long n_per_ch, long ch_stride, int C,
              const float *__restrict__ table, const PenT *__restrict__ pen, const float *__restrict__ len,
              int L, uint16_t *__restrict__ out_idx, float *__restrict__ out_zhat,
              float *__restrict__ out_bits, long E, int vec_ok) {
@@ -177,7 +177,7 @@ k_quant_flat(const float *__restrict__ mu, const float *__restrict__ sg, long n_
     for (int i = threadIdx.x; i < T; i += blockDim.x) tb[i] = table[(long)c * T + i];
     __syncthreads();
 
-    const long base = (long)c * n_per_ch;
+    const long base = (long)c * ch_stride;
     const long nquads = (n_per_ch + 3) >> 2;
     for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < nquads; q += (long)gridDim.x * blockDim.x) {
         const long i0 = q * 4;
@@ -330,12 +330,16 @@ inline bool force_plain_kernel() {
     return v;
 }
 
+// Rows [row_begin, row_end) of the full [n_rows x n_ch] arrays are processed; outputs keep the full arrays'
+// addressing (lambda planes E = n_rows * n_ch apart).  level_counts != NULL: counting mode of the fast kernel.
 template <int N, typename PenT>
 int launch_quantize(const float *mu, const float *sg, int64_t n_rows, int32_t n_ch, int32_t layout,
                     const float *table, const float *level_len, const double *h_lambdas, int32_t L,
-                    uint16_t *out_idx, float *out_zhat, float *out_bits, void *ws, hipStream_t st) {
+                    uint16_t *out_idx, float *out_zhat, float *out_bits, void *ws, int64_t row_begin, int64_t row_end,
+                    unsigned long long *level_counts, int wg_per_cu, hipStream_t st) {
     constexpr int N1 = N + 1;
     const int64_t E = n_rows * (int64_t)n_ch;
+    const int64_t n_sub = row_end - row_begin;
     PenT *pen = reinterpret_cast<PenT *>(ws);
     // the last 64 bytes of the workspace hold the "odd penalties" flag (see k_prepare_penalties)
     const int Lmax = L < kMaxLambdaChunk ? L : kMaxLambdaChunk;
@@ -358,13 +362,19 @@ int launch_quantize(const float *mu, const float *sg, int64_t n_rows, int32_t n_
                            (int)n_ch, N1, len_c, pen, odd);
         VBQ_CHECK_LAUNCH("prepare_penalties");
 
-        uint16_t *oi = out_idx + (int64_t)l0 * E;
-        float *oz = out_zhat ? out_zhat + (int64_t)l0 * E : nullptr;
-        float *ob = out_bits ? out_bits + (int64_t)l0 * E : nullptr;
+        // element offset of the first processed row: planes / one code book -> row_begin, channel-last -> row_begin * C
+        const int64_t off = (flat && !bc_to_cb) ? row_begin : row_begin * n_ch;
+        const int64_t off_out = flat ? row_begin : row_begin * n_ch;
+        const float *mu_r = mu + off, *sg_r = sg + off;
+        uint16_t *oi = out_idx ? out_idx + (int64_t)l0 * E + off_out : nullptr;
+        float *oz = out_zhat ? out_zhat + (int64_t)l0 * E + off_out : nullptr;
+        float *ob = out_bits ? out_bits + (int64_t)l0 * E + off_out : nullptr;
+        unsigned long long *lc_out = level_counts ? level_counts + (int64_t)l0 * n_ch * N1 : nullptr;
         if (flat) {
-            const int64_t n_per_ch = (n_ch == 1) ? E : n_rows;
-            const int vec_ok = ((n_per_ch % 4 == 0) || n_ch == 1) &&
-                               ((reinterpret_cast<uintptr_t>(mu) | reinterpret_cast<uintptr_t>(sg)) % 16 == 0) &&
+            const int64_t n_per_ch = n_sub;                    // per channel (n_ch == 1: the whole range)
+            const int64_t ch_stride = n_rows;
+            const int vec_ok = ((n_rows % 4 == 0) || n_ch == 1) &&
+                               ((reinterpret_cast<uintptr_t>(mu_r) | reinterpret_cast<uintptr_t>(sg_r)) % 16 == 0) &&
                                (reinterpret_cast<uintptr_t>(oi) % 8 == 0) && (E % 4 == 0 || L == 1) &&
                                (!oz || reinterpret_cast<uintptr_t>(oz) % 16 == 0) &&
                                (!ob || reinterpret_cast<uintptr_t>(ob) % 16 == 0);
@@ -379,19 +389,24 @@ int launch_quantize(const float *mu, const float *sg, int64_t n_rows, int32_t n_
             for (int i = 0; i < Lc; ++i) fast_ok = fast_ok && (lc.lam[i] >= 1.9e-12 && lc.lam[i] <= 1.8e19);
             if constexpr (sizeof(PenT) == 4) {
                 if (fast_ok) {
-                    const int r = launch_quant_fast<N>(mu, sg, n_per_ch, n_ch, table, pen, len_c, Lc, oi, oz, ob, E,
-                                                       vec_ok | (bc_to_cb ? 2 : 0), odd, st);
+                    const int r = launch_quant_fast<N>(mu_r, sg_r, n_per_ch, ch_stride, n_ch, table, pen, len_c, Lc, oi, oz, ob,
+                                                       E, vec_ok | (bc_to_cb ? 2 : 0), odd, lc_out, wg_per_cu, st);
                     if (r != VBQ_OK) return r;
                     continue;
                 }
+            }
+            if (level_counts) {
+                set_error("vbq_level_counts_f32 is served by the fast f32 kernel only (every lambda in [1.9e-12, 1.8e19]); "
+                          "use vbq_quantize_f32 + vbq_histogram_u16 instead");
+                return VBQ_ERR_UNSUPPORTED;
             }
             if (bc_to_cb) {
                 set_error("vbq_quantize_f32: VBQ_LAYOUT_BC_TO_CB is served by the fast f32 kernel only (VBQ_MODE_F32, every "
                           "lambda in [1.9e-12, 1.8e19]); transpose with vbq_transpose_f32 and use VBQ_LAYOUT_CB instead");
                 return VBQ_ERR_UNSUPPORTED;
             }
-            hipLaunchKernelGGL((k_quant_flat<N, PenT>), dim3((unsigned)gx, (unsigned)n_ch), dim3(256), 0, st, mu, sg,
-                               (long)n_per_ch, (int)n_ch, table, pen, len_c, Lc, oi, oz, ob, (long)E, vec_ok);
+            hipLaunchKernelGGL((k_quant_flat<N, PenT>), dim3((unsigned)gx, (unsigned)n_ch), dim3(256), 0, st, mu_r, sg_r,
+                               (long)n_per_ch, (long)ch_stride, (int)n_ch, table, pen, len_c, Lc, oi, oz, ob, (long)E, vec_ok);
             VBQ_CHECK_LAUNCH("quant_flat");
         } else if constexpr (N > 10) {
             set_error("vbq_quantize_f32: N=%d is built for channel-major planes only (VBQ_LAYOUT_CB, or n_ch = 1): "
@@ -411,12 +426,12 @@ int launch_quantize(const float *mu, const float *sg, int64_t n_rows, int32_t n_
                 }
             }
             const int groups = (n_ch + kTileChannels - 1) / kTileChannels;
-            int64_t iters = (n_rows + kRowsPerIter - 1) / kRowsPerIter;
+            int64_t iters = (n_sub + kRowsPerIter - 1) / kRowsPerIter;
             int64_t gx = (256 + groups - 1) / groups;          // one workgroup per CU
             if (gx > iters) gx = iters;
             if (gx < 1) gx = 1;
             hipLaunchKernelGGL((k_quant_tiled<N, PenT>), dim3((unsigned)gx, (unsigned)groups), dim3(kTiledThreads),
-                               lds, st, mu, sg, (long)n_rows, (int)n_ch, table, pen, len_c, Lc, oi, oz, ob, (long)E);
+                               lds, st, mu_r, sg_r, (long)n_sub, (int)n_ch, table, pen, len_c, Lc, oi, oz, ob, (long)E);
             VBQ_CHECK_LAUNCH("quant_tiled");
         }
     }
@@ -432,50 +447,82 @@ extern "C" size_t vbq_quantize_workspace_bytes(int32_t n_ch, int32_t n_lambda, i
     return (size_t)Lc * (size_t)n_ch * (size_t)(N + 1) * sizeof(double) + 256;
 }
 
-extern "C" int vbq_quantize_f32(const float *d_mu, const float *d_sigma, int64_t n_rows, int32_t n_ch,
-                                int32_t layout, const float *d_table_lm, const float *d_level_len,
-                                const double *h_lambdas, int32_t n_lambda, int32_t N, int32_t mode,
-                                uint16_t *d_out_idx, float *d_out_zhat, float *d_out_bits, void *d_workspace,
-                                size_t workspace_bytes, void *stream) {
-    using namespace vbq;
+namespace vbq {
+namespace {
+int quantize_entry(const char *who, const float *d_mu, const float *d_sigma, int64_t n_rows, int32_t n_ch, int32_t layout,
+                   const float *d_table_lm, const float *d_level_len, const double *h_lambdas, int32_t n_lambda,
+                   int32_t N, int32_t mode, uint16_t *d_out_idx, float *d_out_zhat, float *d_out_bits,
+                   void *d_workspace, size_t workspace_bytes, int64_t row_begin, int64_t row_end,
+                   unsigned long long *level_counts, int32_t wg_per_cu, void *stream) {
+    const bool counting = level_counts != nullptr;
     VBQ_REQUIRE(n_rows >= 0 && n_ch >= 1 && n_lambda >= 1, VBQ_ERR_INVALID_ARGUMENT,
-                "vbq_quantize_f32: bad sizes n_rows=%lld n_ch=%d n_lambda=%d", (long long)n_rows, n_ch, n_lambda);
-    VBQ_REQUIRE(n_rows == 0 || (d_mu && d_sigma && d_table_lm && h_lambdas && d_out_idx), VBQ_ERR_INVALID_ARGUMENT,
-                "vbq_quantize_f32: null pointer argument");
+                "%s: bad sizes n_rows=%lld n_ch=%d n_lambda=%d", who, (long long)n_rows, n_ch, n_lambda);
+    VBQ_REQUIRE(0 <= row_begin && row_begin <= row_end && row_end <= n_rows, VBQ_ERR_INVALID_ARGUMENT,
+                "%s: row range [%lld, %lld) outside [0, %lld)", who, (long long)row_begin, (long long)row_end, (long long)n_rows);
+    VBQ_REQUIRE(row_begin == row_end || (d_mu && d_sigma && d_table_lm && h_lambdas && (d_out_idx || counting)),
+                VBQ_ERR_INVALID_ARGUMENT, "%s: null pointer argument", who);
     VBQ_REQUIRE(layout == VBQ_LAYOUT_BC || layout == VBQ_LAYOUT_CB || layout == VBQ_LAYOUT_BC_TO_CB, VBQ_ERR_INVALID_ARGUMENT,
-                "vbq_quantize_f32: unknown layout %d", layout);
-    VBQ_REQUIRE(mode == VBQ_MODE_F32 || mode == VBQ_MODE_F64_SCORE, VBQ_ERR_INVALID_ARGUMENT,
-                "vbq_quantize_f32: unknown mode %d", mode);
+                "%s: unknown layout %d", who, layout);
+    VBQ_REQUIRE(mode == VBQ_MODE_F32 || mode == VBQ_MODE_F64_SCORE, VBQ_ERR_INVALID_ARGUMENT, "%s: unknown mode %d", who, mode);
     VBQ_REQUIRE(!(mode == VBQ_MODE_F64_SCORE && d_level_len), VBQ_ERR_UNSUPPORTED,
-                "vbq_quantize_f32: VBQ_MODE_F64_SCORE supports raw integer lengths only");
-    VBQ_REQUIRE(n_ch <= 65535, VBQ_ERR_UNSUPPORTED, "vbq_quantize_f32: n_ch=%d exceeds 65535", n_ch);
+                "%s: VBQ_MODE_F64_SCORE supports raw integer lengths only", who);
+    VBQ_REQUIRE(n_ch <= 65535, VBQ_ERR_UNSUPPORTED, "%s: n_ch=%d exceeds 65535", who, n_ch);
+    VBQ_REQUIRE(wg_per_cu >= 0 && wg_per_cu <= 5, VBQ_ERR_INVALID_ARGUMENT, "%s: workgroups_per_cu=%d not in 0..5", who, wg_per_cu);
+    VBQ_REQUIRE(!counting || n_ch == 1 || layout != VBQ_LAYOUT_BC, VBQ_ERR_UNSUPPORTED,
+                "%s: channel-last input with n_ch > 1 is not served (use VBQ_LAYOUT_CB planes or VBQ_LAYOUT_BC_TO_CB)", who);
     const size_t need = vbq_quantize_workspace_bytes(n_ch, n_lambda, N);
-    VBQ_REQUIRE(d_workspace && workspace_bytes >= need, VBQ_ERR_WORKSPACE,
-                "vbq_quantize_f32: workspace of %zu bytes given, %zu needed", workspace_bytes, need);
-    if (n_rows == 0) return VBQ_OK;
+    VBQ_REQUIRE(d_workspace && workspace_bytes >= need, VBQ_ERR_WORKSPACE, "%s: workspace of %zu bytes given, %zu needed", who,
+                workspace_bytes, need);
+    if (row_begin == row_end) return VBQ_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 #define VBQ_DISPATCH_N(NN)                                                                                         \
     case NN:                                                                                                       \
         return mode == VBQ_MODE_F32                                                                                \
                    ? launch_quantize<NN, float>(d_mu, d_sigma, n_rows, n_ch, layout, d_table_lm, d_level_len,      \
                                                 h_lambdas, n_lambda, d_out_idx, d_out_zhat, d_out_bits,            \
-                                                d_workspace, st)                                                   \
+                                                d_workspace, row_begin, row_end, level_counts, wg_per_cu, st)      \
                    : launch_quantize<NN, double>(d_mu, d_sigma, n_rows, n_ch, layout, d_table_lm, d_level_len,     \
                                                  h_lambdas, n_lambda, d_out_idx, d_out_zhat, d_out_bits,           \
-                                                 d_workspace, st);
+                                                 d_workspace, row_begin, row_end, level_counts, wg_per_cu, st);
     switch (N) {
-        VBQ_DISPATCH_N(12)
-        VBQ_DISPATCH_N(11)
-        VBQ_DISPATCH_N(10)
-        VBQ_DISPATCH_N(9)
-        VBQ_DISPATCH_N(8)
-        VBQ_DISPATCH_N(7)
-        VBQ_DISPATCH_N(6)
-        VBQ_DISPATCH_N(5)
-        VBQ_DISPATCH_N(4)
+        VBQ_FOR_EACH_N(VBQ_DISPATCH_N)
         default:
-            set_error("vbq_quantize_f32: max_bits_per_coord N=%d not built (have 4 ... 12)", N);
+            set_error("%s: max_bits_per_coord N=%d not built (have 4 ... 12; only 10 with VBQ_ONLY_N10)", who, N);
             return VBQ_ERR_UNSUPPORTED;
     }
 #undef VBQ_DISPATCH_N
+}
+}  // namespace
+}  // namespace vbq
+
+extern "C" int vbq_quantize_f32(const float *d_mu, const float *d_sigma, int64_t n_rows, int32_t n_ch,
+                                int32_t layout, const float *d_table_lm, const float *d_level_len,
+                                const double *h_lambdas, int32_t n_lambda, int32_t N, int32_t mode,
+                                uint16_t *d_out_idx, float *d_out_zhat, float *d_out_bits, void *d_workspace,
+                                size_t workspace_bytes, void *stream) {
+    return vbq::quantize_entry("vbq_quantize_f32", d_mu, d_sigma, n_rows, n_ch, layout, d_table_lm, d_level_len, h_lambdas,
+                               n_lambda, N, mode, d_out_idx, d_out_zhat, d_out_bits, d_workspace, workspace_bytes, 0,
+                               n_rows, nullptr, 0, stream);
+}
+
+extern "C" int vbq_quantize_rows_f32(const float *d_mu, const float *d_sigma, int64_t n_rows, int32_t n_ch,
+                                     int32_t layout, const float *d_table_lm, const float *d_level_len,
+                                     const double *h_lambdas, int32_t n_lambda, int32_t N, int32_t mode,
+                                     uint16_t *d_out_idx, float *d_out_zhat, float *d_out_bits, void *d_workspace,
+                                     size_t workspace_bytes, int64_t row_begin, int64_t row_end,
+                                     int32_t workgroups_per_cu, void *stream) {
+    return vbq::quantize_entry("vbq_quantize_rows_f32", d_mu, d_sigma, n_rows, n_ch, layout, d_table_lm, d_level_len,
+                               h_lambdas, n_lambda, N, mode, d_out_idx, d_out_zhat, d_out_bits, d_workspace, workspace_bytes,
+                               row_begin, row_end, nullptr, workgroups_per_cu, stream);
+}
+
+extern "C" int vbq_level_counts_f32(const float *d_mu, const float *d_sigma, int64_t n_rows, int32_t n_ch,
+                                    int32_t layout, const float *d_table_lm, const float *d_level_len,
+                                    const double *h_lambdas, int32_t n_lambda, int32_t N, int64_t *d_level_counts,
+                                    void *d_workspace, size_t workspace_bytes, void *stream) {
+    using namespace vbq;
+    VBQ_REQUIRE(n_rows == 0 || d_level_counts, VBQ_ERR_INVALID_ARGUMENT, "vbq_level_counts_f32: null pointer argument");
+    return quantize_entry("vbq_level_counts_f32", d_mu, d_sigma, n_rows, n_ch, layout, d_table_lm, d_level_len, h_lambdas,
+                          n_lambda, N, VBQ_MODE_F32, nullptr, nullptr, nullptr, d_workspace, workspace_bytes, 0, n_rows,
+                          reinterpret_cast<unsigned long long *>(d_level_counts), 0, stream);
 }

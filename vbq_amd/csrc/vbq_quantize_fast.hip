@@ -144,15 +144,23 @@ __device__ VBQ_SLOW_INLINE uint32_t exact_rank_scan(const float *tb, float z, fl
     return (bestL <= bestR) ? rkL : rkR;       // every L precedes every R in the reference order
 }
 
-template <int N, bool EXTRA>
+// MODE 0: rank indices; 1: + Z_hat / code lengths; 2: no per-element output at all -- the bit LEVEL of every
+// winner is counted per (lambda, channel) (the np.bincount(raw_num_bits) of quantizer.py:104), which is all the
+// first entropy-model pass needs: no 2 B per solve written, no K2 pass reading them back.  The LDS column that
+// parks the packed rank / gap words in modes 0 / 1 holds the counters instead: [L][N+1] x 32 sixteen-bit copies
+// (16 words x 2 halves per (lambda, level); lane & 15 picks the word, lane & 16 the half).
+template <int N, int MODE>
 __global__ void __launch_bounds__(kFastThreads, VBQ_FAST_WAVES)
-k_quant_fast(const float *__restrict__ mu, const float *__restrict__ sg, long n_per_ch, int C,
+k_quant_fast(const float *__restrict__ mu, const float *__restrict__ sg, long n_per_ch, long ch_stride, int C,
              const float *__restrict__ table, const float *__restrict__ pen, const float *__restrict__ len,
              int L, uint16_t *__restrict__ out_idx, float *__restrict__ out_zhat,
-             float *__restrict__ out_bits, long E, int vec_ok, int dbg, const unsigned int *__restrict__ odd_pen) {
+             float *__restrict__ out_bits, long E, int vec_ok, int dbg, const unsigned int *__restrict__ odd_pen,
+             unsigned long long *__restrict__ level_counts) {
     constexpr int T = table_size(N);
     constexpr int N1 = N + 1;
     constexpr int NE = kFastNE;
+    constexpr bool EXTRA = MODE == 1;
+    constexpr bool COUNT = MODE == 2;
     // dbg (tests only, VBQ_FAST_DEBUG): 1 = send every solve through the literal scan,
     // 2 = never flag (shows that the flags are what keeps the fast path exact)
     // *odd_pen != 0: a caller-supplied length table left the range the tie certificate assumes -> literal scan
@@ -162,6 +170,9 @@ k_quant_fast(const float *__restrict__ mu, const float *__restrict__ sg, long n_
     __shared__ uint32_t scratch[N1 * NE * kFastThreads];
     __shared__ __align__(16) float penl[kMaxLambdaChunk * PS];
     const int c = blockIdx.y;
+    if (COUNT) {
+        for (int i = threadIdx.x; i < N1 * NE * kFastThreads; i += blockDim.x) scratch[i] = 0;
+    }
     for (int i = threadIdx.x; i < T; i += blockDim.x) tb[i] = table[(long)c * T + i];
     for (int i = threadIdx.x; i < L * PS; i += blockDim.x) {
         const int l = i / PS, n = i - l * PS;
@@ -169,7 +180,7 @@ k_quant_fast(const float *__restrict__ mu, const float *__restrict__ sg, long n_
     }
     __syncthreads();
 
-    const long base = (long)c * n_per_ch;
+    const long base = (long)c * ch_stride;
     const long nquads = (n_per_ch + NE - 1) / NE;
 
     for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < nquads; q += (long)gridDim.x * blockDim.x) {
@@ -245,8 +256,10 @@ k_quant_fast(const float *__restrict__ mu, const float *__restrict__ sg, long n_
                     dL = dist_cost(*reinterpret_cast<const float *>(tbb + off4 + lo4), m4[k], rinv[k]);
                     dR = dist_cost(*reinterpret_cast<const float *>(tbb + off4 + hi4), m4[k], rinv[k]);
                 }
-                const bool r_better = dR < dL;                  // strict: on equal costs L keeps the level
                 du[k][n] = fminf(dL, dR);
+                g[k] = 2 * g[k] + (below ? 4u : 0u);
+                if (COUNT) continue;                           // the level alone is wanted: no rank, no gap
+                const bool r_better = dR < dL;                  // strict: on equal costs L keeps the level
                 const uint32_t b4 = r_better ? hi4 : lo4;
                 // rank index ((2 pos + 1) << (N - n)) - 1 of the better side, from 4 * pos
                 const uint32_t better = n < N ? (b4 << (N - n - 1)) + ((1u << (N - n)) - 1u) : (b4 >> 1);
@@ -254,7 +267,6 @@ k_quant_fast(const float *__restrict__ mu, const float *__restrict__ sg, long n_
                 // when R is the better side, and >= 2^31 -- never "close" -- when L is (dR - dL >= +0)
                 const uint32_t gap = __float_as_uint(__fsub_rn(dR, dL)) ^ 0x80000000u;
                 scratch[(n * NE + k) * kFastThreads + threadIdx.x] = (gap & kWordMask) | better;
-                g[k] = 2 * g[k] + (below ? 4u : 0u);
             }
         }
 
@@ -284,6 +296,33 @@ k_quant_fast(const float *__restrict__ mu, const float *__restrict__ sg, long n_
 #pragma unroll
                     for (int k = 0; k < NE; ++k)
                         ne[k] = __builtin_amdgcn_alignbit(ne[k], __float_as_uint(__fsub_rn(S[k], cst[k][n])), 31);
+            }
+            uint64_t fmk[NE];
+            if constexpr (COUNT) {
+                // level of the winner = shallowest level attaining S, unless several levels attain it (then the
+                // reference's L-before-R order decides: literal scan).  Which SIDE wins never changes the level.
+                uint64_t any_multi = 0;
+                uint32_t lvl[NE];
+#pragma unroll
+                for (int k = 0; k < NE; ++k) {
+                    lvl[k] = (uint32_t)__builtin_ctz(~ne[k]);
+                    const uint64_t multi = __builtin_amdgcn_uicmp((uint32_t)__popc(ne[k]), (uint32_t)N, 33);
+                    fmk[k] = never_flag ? 0ull : (force_slow ? ~0ull : multi);
+                    any_multi |= fmk[k];
+                }
+                if (any_multi != 0) {
+                    const uint32_t lane = __lane_id();
+#pragma unroll
+                    for (int k = 0; k < NE; ++k)
+                        if ((fmk[k] >> lane) & 1ull)
+                            lvl[k] = (uint32_t)N - (uint32_t)__builtin_ctz(exact_rank_scan<N>(tb, m4[k], s4[k], pp) + 1u);
+                }
+                const uint32_t lane = threadIdx.x & 63u;
+                const uint32_t inc = (lane & 16u) ? 0x10000u : 1u;
+#pragma unroll
+                for (int k = 0; k < NE; ++k)
+                    if (i0 + k < n_per_ch) atomicAdd(&scratch[((uint32_t)(l * N1) + lvl[k]) * 16u + (lane & 15u)], inc);
+                continue;
             }
             uint32_t pk[NE];
 #pragma unroll
@@ -360,18 +399,34 @@ k_quant_fast(const float *__restrict__ mu, const float *__restrict__ sg, long n_
             }
         }
     }
+    if constexpr (COUNT) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < L * N1; i += blockDim.x) {
+            unsigned int v = 0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const unsigned int w = scratch[i * 16 + j];
+                v += (w & 0xffffu) + (w >> 16);
+            }
+            const int l = i / N1, n = i - l * N1;
+            if (v) atomicAdd(&level_counts[((long)l * C + c) * N1 + n], (unsigned long long)v);
+        }
+    }
 }
 
 }  // namespace
 
 template <int N>
-int launch_quant_fast(const float *mu, const float *sg, int64_t n_per_ch, int32_t n_ch, const float *table,
+int launch_quant_fast(const float *mu, const float *sg, int64_t n_per_ch, int64_t ch_stride, int32_t n_ch, const float *table,
                       const float *pen, const float *len, int32_t L, uint16_t *out_idx, float *out_zhat,
-                      float *out_bits, int64_t E, int vec_ok, const unsigned int *odd_pen, hipStream_t st) {
+                      float *out_bits, int64_t E, int vec_ok, const unsigned int *odd_pen,
+                      unsigned long long *level_counts, int wg_per_cu, hipStream_t st) {
     const int64_t nquads = (n_per_ch + kFastNE - 1) / kFastNE;
     int64_t gx = (nquads + kFastThreads - 1) / kFastThreads;
-    // 3 (NE=4: 53 KB LDS each) / 5 (NE=2) workgroups per CU fit; keep every channel's share balanced
-    int64_t cap = (int64_t)256 * (kFastNE == 4 ? 3 : 5) * 4 / n_ch;
+    // 3 (NE=4: 53 KB LDS each) / 5 (NE=2) workgroups per CU fit; keep every channel's share balanced.
+    // wg_per_cu < 5 leaves LDS and wave slots for a kernel of another stream (K2 overlapping this launch).
+    const int per_cu = kFastNE == 4 ? 3 : (wg_per_cu >= 1 && wg_per_cu <= 5 ? wg_per_cu : 5);
+    int64_t cap = (int64_t)256 * per_cu * (wg_per_cu >= 1 ? 1 : 4) / n_ch;
     if (cap < 1) cap = 1;
     if (gx > cap) {
         // every workgroup walks ceil(iters / gx) chunks: pick the gx in [cap/2, cap] that wastes the
@@ -383,37 +438,30 @@ int launch_quant_fast(const float *mu, const float *sg, int64_t n_per_ch, int32_
             if (pad * best < best_pad * g) { best = g; best_pad = pad; }
         }
         gx = best;
+        // count mode: 16-bit partial counters take 16 per iteration at most
+        if (level_counts && (iters + gx - 1) / gx > 4000) gx = (iters + 3999) / 4000;
     }
     if (gx < 1) gx = 1;
     const dim3 grid((unsigned)gx, (unsigned)n_ch), block(kFastThreads);
     static const int dbg = [] { const char *e = getenv("VBQ_FAST_DEBUG"); return e ? atoi(e) : 0; }();
-    if (out_zhat || out_bits)
-        hipLaunchKernelGGL((k_quant_fast<N, true>), grid, block, 0, st, mu, sg, (long)n_per_ch, (int)n_ch, table, pen,
-                           len, (int)L, out_idx, out_zhat, out_bits, (long)E, vec_ok, dbg, odd_pen);
+    if (level_counts)
+        hipLaunchKernelGGL((k_quant_fast<N, 2>), grid, block, 0, st, mu, sg, (long)n_per_ch, (long)ch_stride, (int)n_ch, table,
+                           pen, len, (int)L, out_idx, out_zhat, out_bits, (long)E, vec_ok, dbg, odd_pen, level_counts);
+    else if (out_zhat || out_bits)
+        hipLaunchKernelGGL((k_quant_fast<N, 1>), grid, block, 0, st, mu, sg, (long)n_per_ch, (long)ch_stride, (int)n_ch, table,
+                           pen, len, (int)L, out_idx, out_zhat, out_bits, (long)E, vec_ok, dbg, odd_pen, level_counts);
     else
-        hipLaunchKernelGGL((k_quant_fast<N, false>), grid, block, 0, st, mu, sg, (long)n_per_ch, (int)n_ch, table, pen,
-                           len, (int)L, out_idx, out_zhat, out_bits, (long)E, vec_ok, dbg, odd_pen);
+        hipLaunchKernelGGL((k_quant_fast<N, 0>), grid, block, 0, st, mu, sg, (long)n_per_ch, (long)ch_stride, (int)n_ch, table,
+                           pen, len, (int)L, out_idx, out_zhat, out_bits, (long)E, vec_ok, dbg, odd_pen, level_counts);
     VBQ_CHECK_LAUNCH("quant_fast");
     return VBQ_OK;
 }
 
-template int launch_quant_fast<10>(const float *, const float *, int64_t, int32_t, const float *, const float *,
-                                   const float *, int32_t, uint16_t *, float *, float *, int64_t, int, const unsigned int *, hipStream_t);
-template int launch_quant_fast<12>(const float *, const float *, int64_t, int32_t, const float *, const float *,
-                                  const float *, int32_t, uint16_t *, float *, float *, int64_t, int, const unsigned int *, hipStream_t);
-template int launch_quant_fast<11>(const float *, const float *, int64_t, int32_t, const float *, const float *,
-                                  const float *, int32_t, uint16_t *, float *, float *, int64_t, int, const unsigned int *, hipStream_t);
-template int launch_quant_fast<8>(const float *, const float *, int64_t, int32_t, const float *, const float *,
-                                  const float *, int32_t, uint16_t *, float *, float *, int64_t, int, const unsigned int *, hipStream_t);
-template int launch_quant_fast<9>(const float *, const float *, int64_t, int32_t, const float *, const float *,
-                                  const float *, int32_t, uint16_t *, float *, float *, int64_t, int, const unsigned int *, hipStream_t);
-template int launch_quant_fast<7>(const float *, const float *, int64_t, int32_t, const float *, const float *,
-                                  const float *, int32_t, uint16_t *, float *, float *, int64_t, int, const unsigned int *, hipStream_t);
-template int launch_quant_fast<5>(const float *, const float *, int64_t, int32_t, const float *, const float *,
-                                  const float *, int32_t, uint16_t *, float *, float *, int64_t, int, const unsigned int *, hipStream_t);
-template int launch_quant_fast<6>(const float *, const float *, int64_t, int32_t, const float *, const float *,
-                                  const float *, int32_t, uint16_t *, float *, float *, int64_t, int, const unsigned int *, hipStream_t);
-template int launch_quant_fast<4>(const float *, const float *, int64_t, int32_t, const float *, const float *,
-                                  const float *, int32_t, uint16_t *, float *, float *, int64_t, int, const unsigned int *, hipStream_t);
+#define VBQ_INST_FAST(NN)                                                                                              \
+    template int launch_quant_fast<NN>(const float *, const float *, int64_t, int64_t, int32_t, const float *,        \
+                                       const float *, const float *, int32_t, uint16_t *, float *, float *, int64_t,  \
+                                       int, const unsigned int *, unsigned long long *, int, hipStream_t);
+VBQ_FOR_EACH_N(VBQ_INST_FAST)
+#undef VBQ_INST_FAST
 
 }  // namespace vbq

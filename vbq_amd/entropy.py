@@ -38,6 +38,23 @@ def neg_log2_freq(counts, add_n_smoothing) -> np.ndarray:
     return (-np.log2(freqs)).reshape(lead + (c.shape[-1],))
 
 
+def neg_log2_lut(total_count: int, K: int, add_n_smoothing, max_entries: int = 1 << 24):
+    """Table form of `neg_log2_freq` for rows that all hold the same number of samples: lut[k] =
+    -log2(f32(k + n) / f32(total_count + K n)) for k = 0..total_count, computed with the reference's own NumPy float32
+    operations (quantizer.py:105-109 / 140-144).  Valid -- and returned -- only when those operations do not depend
+    on anything but k: n a non-negative integer and total_count + K n < 2^24, so that counts + n and every partial
+    sum of np.sum are exact integers in float32 and every row's sum is the same number.  Otherwise None (the caller
+    then runs `neg_log2_freq` on the counts themselves)."""
+    n = float(add_n_smoothing)
+    if not (n >= 0 and n.is_integer()) or total_count < 0 or total_count + K * n >= 2 ** 24 or total_count + 1 > max_entries:
+        return None
+    k = np.arange(total_count + 1, dtype=np.float32)
+    k += add_n_smoothing
+    total = np.float32(total_count + K * n)
+    with np.errstate(divide="ignore"):
+        return (-np.log2(k / total)).astype(np.float32)
+
+
 def level_lengths_from_counts(counts: torch.Tensor, N: int, add_n_smoothing=1) -> torch.Tensor:
     """Pass-1 rank histogram [L, C, T] -> corrected level lengths f32 [L, C, N+1]
     = n + raw_code_length_entropy_model (quantizer.py:104-110, 171-175)."""

@@ -55,15 +55,19 @@ def quantize(mu: torch.Tensor, sigma: torch.Tensor, table_lm: torch.Tensor, lamb
              N: int = 10, level_len: Optional[torch.Tensor] = None, layout="bc", mode="f32",
              want_zhat: bool = False, want_bits: bool = False, out_idx: Optional[torch.Tensor] = None,
              out_zhat: Optional[torch.Tensor] = None, out_bits: Optional[torch.Tensor] = None,
-             workspace: Optional[torch.Tensor] = None):
+             workspace: Optional[torch.Tensor] = None, rows: Optional[Sequence[int]] = None,
+             workgroups_per_cu: int = 0):
     """K1 (vbq_quantize_f32).  mu, sigma: f32 [rows, C] (layout 'bc') / [C, rows] ('cb') / [n] (C = 1).
     table_lm: f32 [C, T] level-major.  level_len: optional f32 [L, C, N+1].
     Returns idx u16 [L, *mu.shape] and, when asked, zhat / bits f32 of the same shape.
     layout 'bc->cb': inputs channel-last [rows, C], outputs channel-major planes [L, C, rows] (no input transposes;
-    f32 mode and lambdas in the fast kernel's range only, VBQError otherwise)."""
+    f32 mode and lambdas in the fast kernel's range only, VBQError otherwise).
+    rows=(r0, r1): only that row range is solved (vbq_quantize_rows_f32; the output tensors are still full-size) --
+    the host cuts a pass into chunks to overlap K2 with K1; workgroups_per_cu: see include/vbq.h."""
     to_planes = layout in ("bc->cb", LAYOUT_BC_TO_CB)
     layout = LAYOUT_BC if to_planes else _LAYOUTS[layout]
     mode = _MODES[mode]
+    rows_range = rows
     mu = _dev(mu, torch.float32, "mu")
     sigma = _dev(sigma, torch.float32, "sigma")
     if mu.shape != sigma.shape:
@@ -104,15 +108,78 @@ def quantize(mu: torch.Tensor, sigma: torch.Tensor, table_lm: torch.Tensor, lamb
     if mu.numel() == 0:
         out = (idx,) + ((zhat,) if want_zhat else ()) + ((bits,) if want_bits else ())
         return out if len(out) > 1 else idx
-    check(h.vbq_quantize_f32(_ptr(mu), _ptr(sigma), rows, Cc, layout, _ptr(table_lm), _ptr(level_len),
-                             _doubles(lambdas), L, N, mode, _ptr(idx), _ptr(zhat), _ptr(bits), _ptr(ws), wsb,
-                             _stream(mu)), "vbq_quantize_f32")
+    if rows_range is None and not workgroups_per_cu:
+        check(h.vbq_quantize_f32(_ptr(mu), _ptr(sigma), rows, Cc, layout, _ptr(table_lm), _ptr(level_len),
+                                 _doubles(lambdas), L, N, mode, _ptr(idx), _ptr(zhat), _ptr(bits), _ptr(ws), wsb,
+                                 _stream(mu)), "vbq_quantize_f32")
+    else:
+        r0, r1 = (0, rows) if rows_range is None else (int(rows_range[0]), int(rows_range[1]))
+        check(h.vbq_quantize_rows_f32(_ptr(mu), _ptr(sigma), rows, Cc, layout, _ptr(table_lm), _ptr(level_len),
+                                      _doubles(lambdas), L, N, mode, _ptr(idx), _ptr(zhat), _ptr(bits), _ptr(ws), wsb,
+                                      r0, r1, int(workgroups_per_cu), _stream(mu)), "vbq_quantize_rows_f32")
     out = (idx,)
     if want_zhat:
         out += (zhat,)
     if want_bits:
         out += (bits,)
     return out if len(out) > 1 else idx
+
+
+def level_counts(mu: torch.Tensor, sigma: torch.Tensor, table_lm: torch.Tensor, lambdas: Sequence[float], *,
+                 N: int = 10, level_len: Optional[torch.Tensor] = None, layout="bc", out: Optional[torch.Tensor] = None,
+                 workspace: Optional[torch.Tensor] = None):
+    """K1h (vbq_level_counts_f32): the solve of `quantize` followed by the per-(lambda, channel) histogram of the
+    winners' bit levels, in one kernel with no per-element output.  Returns int64 [L, C, N+1] (added into `out`)."""
+    to_planes = layout in ("bc->cb", LAYOUT_BC_TO_CB)
+    layout = LAYOUT_BC if to_planes else _LAYOUTS[layout]
+    mu = _dev(mu, torch.float32, "mu")
+    sigma = _dev(sigma, torch.float32, "sigma")
+    if mu.shape != sigma.shape:
+        raise ValueError(f"mu {tuple(mu.shape)} and sigma {tuple(sigma.shape)} differ in shape")
+    rows, Cc = _rows_channels(mu.shape, layout)
+    T = table_size(N)
+    table_lm = _dev(table_lm, torch.float32, "table_lm")
+    if table_lm.numel() != Cc * T:
+        raise ValueError(f"table_lm has {table_lm.numel()} entries, expected C*T = {Cc}*{T}")
+    L = len(lambdas)
+    if L < 1:
+        raise ValueError("need at least one lambda")
+    if level_len is not None:
+        level_len = _dev(level_len, torch.float32, "level_len")
+        if tuple(level_len.shape) != (L, Cc, N + 1):
+            raise ValueError(f"level_len shape {tuple(level_len.shape)} != {(L, Cc, N + 1)}")
+    if to_planes and mu.dim() == 2 and Cc > 1:
+        layout = LAYOUT_BC_TO_CB
+    if out is None:
+        out = torch.zeros((L, Cc, N + 1), dtype=torch.int64, device=mu.device)
+    elif tuple(out.shape) != (L, Cc, N + 1) or out.dtype != torch.int64 or not out.is_cuda or not out.is_contiguous():
+        raise ValueError(f"out: expected a contiguous int64 device tensor of shape {(L, Cc, N + 1)}")
+    h = _lib.lib()
+    wsb = h.vbq_quantize_workspace_bytes(Cc, L, N)
+    ws = workspace if workspace is not None else torch.empty(wsb, dtype=torch.uint8, device=mu.device)
+    if ws.numel() * ws.element_size() < wsb or not ws.is_cuda:
+        raise ValueError(f"workspace must be a device tensor of at least {wsb} bytes")
+    if mu.numel():
+        check(h.vbq_level_counts_f32(_ptr(mu), _ptr(sigma), rows, Cc, layout, _ptr(table_lm), _ptr(level_len),
+                                     _doubles(lambdas), L, N, _ptr(out), _ptr(ws), wsb, _stream(mu)), "vbq_level_counts_f32")
+    return out
+
+
+def code_lengths_from_counts(counts: torch.Tensor, lut: torch.Tensor, *, level_period: int = 0, want_len: bool = True,
+                             want_model: bool = False):
+    """vbq_code_lengths_from_counts: f32 tensors shaped like `counts` -- (level +) lut[count] and / or lut[count]."""
+    if counts.dtype not in (torch.int64, torch.int32):
+        raise ValueError("counts must be int64 or int32")
+    counts = _dev(counts, counts.dtype, "counts")
+    lut = _dev(lut, torch.float32, "lut")
+    out_len = torch.empty(counts.shape, dtype=torch.float32, device=counts.device) if want_len else None
+    out_model = torch.empty(counts.shape, dtype=torch.float32, device=counts.device) if want_model else None
+    check(_lib.lib().vbq_code_lengths_from_counts(_ptr(counts), int(counts.dtype == torch.int32), counts.numel(), _ptr(lut),
+                                                  lut.numel(), int(level_period), _ptr(out_len), _ptr(out_model),
+                                                  _stream(counts)), "vbq_code_lengths_from_counts")
+    if want_len and want_model:
+        return out_len, out_model
+    return out_len if want_len else out_model
 
 
 def quantize_notebook(means: torch.Tensor, stds: torch.Tensor, codebook_lm: torch.Tensor, betas: Sequence[float], *,
@@ -140,10 +207,11 @@ def quantize_notebook(means: torch.Tensor, stds: torch.Tensor, codebook_lm: torc
 
 
 def histogram(idx: torch.Tensor, n_ch: int, *, N: int = 10, layout="bc", out: Optional[torch.Tensor] = None,
-              dtype=torch.int64):
+              dtype=torch.int64, rows: Optional[Sequence[int]] = None):
     """K2 (vbq_histogram_u16 / _i32).  idx: u16 [L, rows, C] / [L, C, rows] / [L, n].  Returns counts
     [L, C, T] (added into `out` when given; `out.dtype` int64 or int32 selects the entry point)."""
     layout = _LAYOUTS[layout]
+    rows_range = rows
     idx = _dev(idx, torch.uint16, "idx")
     L = idx.shape[0]
     E = idx[0].numel()
@@ -162,6 +230,10 @@ def histogram(idx: torch.Tensor, n_ch: int, *, N: int = 10, layout="bc", out: Op
         if tuple(out.shape) != (L, n_ch, T):
             raise ValueError(f"out shape {tuple(out.shape)} != {(L, n_ch, T)}")
     h = _lib.lib()
+    if rows_range is not None:
+        check(h.vbq_histogram_rows_u16(_ptr(idx), rows, n_ch, layout, L, N, _ptr(out), int(out.dtype == torch.int32),
+                                       int(rows_range[0]), int(rows_range[1]), _stream(idx)), "vbq_histogram_rows_u16")
+        return out
     fn, name = (h.vbq_histogram_u16, "vbq_histogram_u16") if out.dtype == torch.int64 else \
                (h.vbq_histogram_u16_i32, "vbq_histogram_u16_i32")
     check(fn(_ptr(idx), rows, n_ch, layout, L, N, _ptr(out), _stream(idx)), name)

@@ -1,0 +1,185 @@
+"""The two-pass entropy-model build of ChannelwisePriorCDFQuantizer.build_entropy_models
+(img-compression/quantizer.py:82-150) as ONE stream-ordered device pipeline:
+
+    pass 1   K1h: solve with the current length table -> histogram of bit levels [L, C, N+1]   (quantizer.py:96-105)
+             (+ all-reduce over ranks)
+    lengths  level counts -> -log2 frequencies -> "n + overhead" table [L, C, N+1]              (:105-112, 171-175)
+    pass 2   K1 with that table -> rank indices [L, C, B]; K2 -> histogram [L, C, T]            (:119-140)
+             (+ all-reduce over ranks); optionally cut into row chunks with K2 of chunk j on a second stream while
+             K1 works on chunk j + 1 (measured: no gain, see __init__)
+    models   rank counts -> -log2 frequencies [L, C, T]                                          (:141-146)
+
+Nothing synchronises with the host when the -log2 step can be tabulated (entropy.neg_log2_lut: every row of a
+histogram holds the same number of samples, so -log2(f32(k + n) / f32(total)) is a function of the count k alone
+and the table is built once, on the host, with the reference's own NumPy float32 operations).  When it cannot
+(2^24 samples per row or more, fractional smoothing) the small level table takes one round trip through the host.
+
+`bench.py` times exactly this object; `ChannelwisePriorCDFQuantizer.build_entropy_models` runs it.
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import entropy as _entropy
+from . import ops
+
+
+def chunk_bounds(rows: int, n_chunks: int, unit: int = 2048):
+    """Row ranges of the overlap chunks: multiples of `unit` rows (4 workgroups x 512 elements per channel keep the
+    persistent K1 grid balanced; any multiple of 8 keeps the vector paths), the remainder in the last chunk."""
+    if n_chunks <= 1 or rows < 2 * unit:
+        return [(0, rows)]
+    units = rows // unit
+    n_chunks = min(n_chunks, units)
+    base, rem = divmod(units, n_chunks)
+    cuts, r = [0], 0
+    for j in range(n_chunks):
+        r += (base + (1 if j < rem else 0)) * unit
+        cuts.append(r)
+    cuts[-1] = rows
+    return list(zip(cuts[:-1], cuts[1:]))
+
+
+class EntropyModelBuild:
+    """Buffers, tables and streams of the alternation for one problem size; `run()` only enqueues work."""
+
+    def __init__(self, rows: int, n_ch: int, lambdas: Sequence[float], table_lm: torch.Tensor, *, N: int = 10,
+                 add_n_smoothing=1, global_rows: Optional[int] = None, distributed: bool = False, group=None,
+                 n_chunks: Optional[int] = None, counts_dtype=None, keep_models: bool = True):
+        self.rows, self.C, self.N = int(rows), int(n_ch), int(N)
+        self.lambdas = [float(l) for l in lambdas]
+        self.L = len(self.lambdas)
+        self.T = ops.table_size(N)
+        self.table = table_lm
+        self.dev = table_lm.device
+        self.smooth = add_n_smoothing
+        self.group = group
+        self.global_rows = int(global_rows if global_rows is not None else rows)
+        # distributed: rows are sharded over the ranks of `group`; the two histograms are summed over them
+        self.world = torch.distributed.get_world_size(group) if distributed else 1
+        L, C, N1, T = self.L, self.C, N + 1, self.T
+        if counts_dtype is None:       # int32 halves the all-reduce payload; exact while no bin can reach 2^31
+            counts_dtype = torch.int32 if self.global_rows < 2 ** 31 else torch.int64
+        self.idx = torch.empty((L, C, self.rows), dtype=torch.uint16, device=self.dev)
+        self.level_counts = torch.zeros((L, C, N1), dtype=torch.int64, device=self.dev)
+        self.counts = torch.zeros((L, C, T), dtype=counts_dtype, device=self.dev)
+        self.ws = torch.empty(ops._lib.lib().vbq_quantize_workspace_bytes(C, L, N), dtype=torch.uint8, device=self.dev)
+        lut1 = _entropy.neg_log2_lut(self.global_rows, N1, add_n_smoothing, max_entries=max(1 << 20, 4 * L * C * N1))
+        lut2 = _entropy.neg_log2_lut(self.global_rows, T, add_n_smoothing, max_entries=max(1 << 20, L * C * T)) if keep_models else None
+        self.lut1 = torch.from_numpy(lut1).to(self.dev) if lut1 is not None else None
+        self.lut2 = torch.from_numpy(lut2).to(self.dev) if lut2 is not None else None
+        self.level_len = torch.empty((L, C, N1), dtype=torch.float32, device=self.dev)
+        self.raw_models = torch.empty((L, C, N1), dtype=torch.float32, device=self.dev)
+        self.models = torch.empty((L, C, T), dtype=torch.float32, device=self.dev) if self.lut2 is not None else None
+        if n_chunks is None:
+            # Measured on the Kodak-24 sweep (profiles/r2_overlap_sweep.txt): K2 one chunk behind K1 on a second stream
+            # is SLOWER than running them back to back (1.06 / 1.10 / 1.19 ms per step with 2 / 3 / 6 chunks against
+            # 0.99 ms) -- K1 saturates the vector ALU, so a co-resident K2 wave only takes issue slots from it.  The
+            # chunked form stays available (n_chunks > 1) for experiments; the default is one launch each.
+            n_chunks = 1
+        self.chunks = chunk_bounds(self.rows, n_chunks)
+        self.k1_workgroups_per_cu = 4  # of 5 that fit: the fifth's LDS and wave slots are K2's while they overlap
+        self.side = torch.cuda.Stream(device=self.dev) if len(self.chunks) > 1 else None
+        self._events = [torch.cuda.Event() for _ in self.chunks] if self.side is not None else []
+        self.reducer = None
+        self.work = None
+        self.timers = None             # bench.py: callable(name, phase) recording an event on the current stream
+        self.collectives = True        # bench.py switches them off to measure what they cost
+        if self.world > 1 and counts_dtype == torch.int32:
+            from .dist import CountsAllReduce
+            self.reducer = CountsAllReduce(L * C * T, self.dev, max_global_count=self.global_rows, group=group)
+
+    # ---------------------------------------------------------------- stages
+    def pass1(self, mu_cb, sg_cb, level_len=None):
+        """quantizer.py:96-105.  level_len: the table of an earlier build, if any (the reference reuses it, :166)."""
+        self.level_counts.zero_()
+        self._t("k1h", 0)
+        ops.level_counts(mu_cb, sg_cb, self.table, self.lambdas, N=self.N, level_len=level_len, layout="cb",
+                         out=self.level_counts, workspace=self.ws)
+        self._t("k1h", 1)
+        if self.world > 1 and self.collectives:
+            torch.distributed.all_reduce(self.level_counts, group=self.group)
+        return self.level_counts
+
+    def _t(self, name, phase):
+        if self.timers is not None:
+            self.timers(name, phase)
+
+    def lengths(self):
+        """quantizer.py:105-112 and the "n + overhead" of :171-175 -> (level_len, raw_models), device f32 [L, C, N+1]."""
+        N1 = self.N + 1
+        if self.lut1 is not None:
+            ops_out = ops._lib.lib().vbq_code_lengths_from_counts
+            ops._lib.check(ops_out(ops._ptr(self.level_counts), 0, self.level_counts.numel(), ops._ptr(self.lut1),
+                                   self.lut1.numel(), N1, ops._ptr(self.level_len), ops._ptr(self.raw_models),
+                                   ops._stream(self.level_counts)), "vbq_code_lengths_from_counts")
+        else:                          # one round trip of an [L, C, N+1] table through the host
+            raw = _entropy.neg_log2_freq(self.level_counts, self.smooth)
+            lv = np.arange(N1, dtype=np.int32).astype(np.float32)
+            self.raw_models.copy_(torch.from_numpy(raw))
+            self.level_len.copy_(torch.from_numpy((lv + raw).astype(np.float32)))
+        return self.level_len, self.raw_models
+
+    def pass2(self, mu_cb, sg_cb, level_len):
+        """quantizer.py:119-140: indices and their per-(lambda, channel) histogram, K2 one chunk behind K1."""
+        self.wait()
+        self.counts.zero_()
+        main = torch.cuda.current_stream(self.dev)
+        if self.side is None:
+            self._t("k1", 0)
+            ops.quantize(mu_cb, sg_cb, self.table, self.lambdas, N=self.N, level_len=level_len, layout="cb",
+                         out_idx=self.idx, workspace=self.ws)
+            self._t("k1", 1)
+            self._t("k2", 0)
+            ops.histogram(self.idx, self.C, N=self.N, layout="cb", out=self.counts)
+            self._t("k2", 1)
+        else:
+            self.side.wait_stream(main)
+            for j, (r0, r1) in enumerate(self.chunks):
+                self._t("k1", 0)
+                ops.quantize(mu_cb, sg_cb, self.table, self.lambdas, N=self.N, level_len=level_len, layout="cb",
+                             out_idx=self.idx, workspace=self.ws, rows=(r0, r1), workgroups_per_cu=self.k1_workgroups_per_cu)
+                self._t("k1", 1)
+                self._events[j].record(main)
+                with torch.cuda.stream(self.side):
+                    self.side.wait_event(self._events[j])
+                    self._t("k2", 0)
+                    ops.histogram(self.idx, self.C, N=self.N, layout="cb", out=self.counts, rows=(r0, r1))
+                    self._t("k2", 1)
+            main.wait_stream(self.side)
+        if self.world > 1 and self.collectives:
+            if self.reducer is not None:
+                self.work = self.reducer.start(self.counts)
+            else:
+                self.work = torch.distributed.all_reduce(self.counts, group=self.group, async_op=True)
+        return self.idx, self.counts
+
+    def wait(self):
+        """The rank histogram's all-reduce (asynchronous, overlapping whatever was enqueued after pass2) is complete
+        for the compute stream after this."""
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+
+    def finish_models(self):
+        """quantizer.py:141-146 -> f32 [L, C, T] on the device (table form), or None when the caller must take the
+        counts to the host (entropy.neg_log2_freq)."""
+        self.wait()
+        if self.lut2 is None:
+            return None
+        ops._lib.check(ops._lib.lib().vbq_code_lengths_from_counts(
+            ops._ptr(self.counts), int(self.counts.dtype == torch.int32), self.counts.numel(), ops._ptr(self.lut2),
+            self.lut2.numel(), 0, None, ops._ptr(self.models), ops._stream(self.counts)), "vbq_code_lengths_from_counts")
+        return self.models
+
+    def run(self, mu_cb, sg_cb, level_len=None, models: bool = True):
+        """One whole alternation; everything is enqueued on the current stream (+ the side stream), nothing waits."""
+        self.pass1(mu_cb, sg_cb, level_len)
+        ll, _ = self.lengths()
+        self.pass2(mu_cb, sg_cb, ll)
+        if models and self.world == 1:
+            self.finish_models()
+        return self

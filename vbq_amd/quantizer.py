@@ -252,13 +252,6 @@ class ChannelwisePriorCDFQuantizer:
         return Z_hat_dict, num_bits_dict
 
     # ------------------------------------------------------------------ entropy models (quantizer.py:82-150)
-    def _counts(self, idx) -> torch.Tensor:
-        cnt = ops.histogram(idx, self.num_channels, N=self.max_bits_per_coord, layout="cb")   # int64 [L, C, T]
-        if self.process_group is not None:
-            import torch.distributed as dist
-            dist.all_reduce(cnt, op=dist.ReduceOp.SUM, group=self.process_group)
-        return cnt
-
     def _encode(self, X, vae):
         posterior_means, posterior_logvars = vae.encode(X)
         m = posterior_means if isinstance(posterior_means, torch.Tensor) else torch.from_numpy(_to_numpy(posterior_means))
@@ -277,30 +270,54 @@ class ChannelwisePriorCDFQuantizer:
         return self.build_entropy_models_from_latents(*self._flatten(means, logvars), lambs, add_n_smoothing)
 
     def build_entropy_models_from_latents(self, batch_means, batch_stds, lambs, add_n_smoothing):
-        """The body of quantizer.py:94-150 on (B x C) means/stds."""
+        """The body of quantizer.py:94-150 on (B x C) means/stds: vbq_amd.pipeline.EntropyModelBuild (pass 1 = solve +
+        bit-length histogram in one kernel, length table on the device, pass 2 = solve with K2 one chunk behind).
+        A rebuild starts from raw lengths again.  (In the reference a second build on the same object would feed the
+        float "n + overhead" lengths of the first one to np.bincount, :96,104,166, which raises TypeError; starting
+        over is the documented divergence)"""
+        from .pipeline import EntropyModelBuild
         lambs = list(lambs)
-        N = self.max_bits_per_coord
+        N, C = self.max_bits_per_coord, self.num_channels
         mu_cb, sg_cb = self._prep(batch_means, batch_stds)
+        B = mu_cb.shape[1]
+        B_global, distributed = B, self.process_group is not None
+        if distributed:
+            import torch.distributed as dist
+            t = torch.tensor([B], dtype=torch.int64, device=self.device)
+            dist.all_reduce(t, group=self.process_group)
+            B_global = int(t.item())
+        build = EntropyModelBuild(B, C, [float(l) for l in lambs], self._table_dev(), N=N, add_n_smoothing=add_n_smoothing,
+                                  global_rows=B_global, distributed=distributed, group=self.process_group,
+                                  counts_dtype=torch.int64, keep_models=self._strict)
         self.raw_code_length_entropy_models = None
-        # pass 1: raw bit lengths -> per-channel histogram of the number of bits (:96-112)
-        idx1 = self._solve_idx(mu_cb, sg_cb, lambs, None)
-        lvl_counts = _entropy.level_counts_from_counts(self._counts(idx1), N)        # [L, C, N+1]
-        raw_models = _entropy.neg_log2_freq(lvl_counts, add_n_smoothing)
+        build.pass1(mu_cb, sg_cb, None)
+        level_len, raw_models = build.lengths()
+        raw_models = raw_models.cpu().numpy()
         self.raw_code_length_entropy_models = {lamb: raw_models[i] for i, lamb in enumerate(lambs)}
         # pass 2: corrected lengths -> per-channel histogram of the code points (:118-148)
-        idx2 = self._solve_idx(mu_cb, sg_cb, lambs, self._level_len_dev(lambs))
-        counts = self._counts(idx2).cpu().numpy()
-        if not self._strict:       # qidx is the FIRST sorted position of a repeated value (:135)
-            merged = np.zeros_like(counts)
-            for c in range(self.num_channels):
-                np.add.at(merged[:, c, :], (slice(None), self._canon[c]), counts[:, c, :])
-            counts = merged
-        models = _entropy.neg_log2_freq(counts, add_n_smoothing)                    # [L, C, T] f32
+        _, counts = build.pass2(mu_cb, sg_cb, level_len)
+        models_dev = build.finish_models()
+        if models_dev is not None:
+            models = models_dev.cpu().numpy()
+            counts = counts.cpu().numpy()
+        else:
+            build.wait()
+            counts = counts.cpu().numpy()
+            if not self._strict:   # qidx is the FIRST sorted position of a repeated value (:135)
+                merged = np.zeros_like(counts)
+                for c in range(self.num_channels):
+                    np.add.at(merged[:, c, :], (slice(None), self._canon[c]), counts[:, c, :])
+                counts = merged
+            models = _entropy.neg_log2_freq(counts, add_n_smoothing)                # [L, C, T] f32
         self.entropy_models = {lamb: models[i] for i, lamb in enumerate(lambs)}
         # kept for the entropy coder (vbq_amd.coder): the integer histograms behind the models
         self._code_counts = {lamb: counts[i] for i, lamb in enumerate(lambs)}
         self._add_n_smoothing = add_n_smoothing
-        self._dev_cache.pop("entropy", None)
+        self._dev_cache.pop("entropy_models", None)
+        self._dev_cache.pop("level_len", None)
+        if models_dev is not None:   # the device copies compress_latents will ask for are already here
+            self._dev_cache["entropy_models"] = ([self.entropy_models[lamb] for lamb in lambs], models_dev)
+        self._dev_cache["level_len"] = ([self.raw_code_length_entropy_models[lamb] for lamb in lambs], level_len)
         return None
 
     @property
@@ -364,6 +381,11 @@ class ChannelwisePriorCDFQuantizer:
         lambs = list(lambs)
         mu_cb, sg_cb = self._prep(batch_means, batch_stds)
         idx = self._solve_idx(mu_cb, sg_cb, lambs, self._level_len_dev(lambs))     # [L, C, B]
+        if not self._strict:
+            # repeated f32 code points: K1 may emit any rank of a run of equal values, the histogram behind the
+            # frequency tables is the canonical one (first position, :135) -- code the canonical index (same Z_hat)
+            canon = self._dev("canon", lambda: torch.from_numpy(self._canon))       # [C, T] int64
+            idx = torch.gather(canon[None].expand(len(lambs), -1, -1), 2, idx.to(torch.int64)).to(torch.uint16)
         cdc = self.codec(lambs, segment)
         words, sizes = cdc.encode(idx)
         return words, sizes, cdc
