@@ -195,7 +195,7 @@ def run_workload(name, args, torch, dist, dev, rank, world, steps, warmup, detai
         mu_in = sg_in = None
         mu, sg = torch.from_numpy(mu_h.reshape(1, rows)).to(dev), torch.from_numpy(sg_h.reshape(1, rows)).to(dev)
     build = EntropyModelBuild(rows, C, LAMBDAS, tab, N=N_BITS, add_n_smoothing=1, global_rows=rows * world,
-                              distributed=world > 1, n_chunks=args.chunks)
+                              distributed=world > 1, level_group=args.level_group, n_chunks=args.chunks)
     if os.environ.get("VBQ_K1_WG_PER_CU"):
         build.k1_workgroups_per_cu = int(os.environ["VBQ_K1_WG_PER_CU"])
     timers = Timers(torch)
@@ -235,8 +235,9 @@ def run_workload(name, args, torch, dist, dev, rank, world, steps, warmup, detai
     timers.enabled = True
     dt = timed(steps)
     timers.enabled = False
-    if build.reducer is not None:
-        build.reducer.check()
+    for r in build.reducers:
+        if r is not None:
+            r.check()                  # the packed counters' overflow guard (one 8-byte read, outside the timed loop)
     eager_ms = dt / steps * 1e3
     launch = "eager launches, two streams" if len(build.chunks) > 1 else "eager launches"
     # The step only enqueues stream-ordered work (no allocation, no host synchronisation when the length table is
@@ -326,7 +327,8 @@ def run_workload(name, args, torch, dist, dev, rank, world, steps, warmup, detai
                             "rank_histogram_allreduce_ms_isolated": ar * 1e3,
                             "ms_per_step_without_collectives": dt0 * 1e3,
                             "exposed_ms_per_step": max(0.0, dt / steps - dt0) * 1e3,
-                            "overlap": "asynchronous: reduces step i's rank histogram while step i+1 computes"}
+                            "overlap": "asynchronous, two buffers: step i's rank histogram is reduced while step i+1 computes; "
+                                       "the bit-length histogram has its own communicator"}
 
     if not detailed or rank != 0:
         del build
@@ -421,6 +423,9 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+
+    # a second communicator for the small, latency-critical all-reduce of the bit-length histogram (see pipeline.py)
+    args.level_group = dist.new_group() if world > 1 else None
 
     if args.notebook:
         out = run_notebook(args, torch, dev)

@@ -309,6 +309,25 @@ int vbq_pack_counts_3x21(const int32_t *d_counts, int64_t n, int64_t *d_words, i
 int vbq_unpack_counts_3x21(const int64_t *d_words, int64_t n, int32_t *d_counts, void *stream);
 
 /* ----------------------------------------------------------------------------------
+ * The one collective of the path: SUM all-reduce of a histogram over the ranks of a node, RCCL over xGMI.
+ * Replaces nothing in the reference (it is single-process); it is what makes quantizer.py:104-105 / 138-140 global
+ * when the rows are sharded over GPUs: every rank ends up with the counts of ALL rows, integer sums, so the
+ * entropy models do not depend on the number of ranks.  One communicator per (process, GPU):
+ *   vbq_comm_unique_id   rank 0 fills VBQ_COMM_ID_BYTES host bytes and hands them to the other ranks by any means
+ *   vbq_comm_init        collective: every rank calls it with the same id (the current HIP device is the rank's GPU)
+ *   vbq_allreduce_hist   in place on d_counts (int64, or int32 when counts_are_i32 != 0), asynchronous on `stream`;
+ *                        works for the level histogram of K1h, the rank histogram of K2 and the packed words of
+ *                        vbq_pack_counts_3x21 (int64) alike
+ *   vbq_comm_destroy
+ * RCCL is bound at run time (dlopen): VBQ_ERR_UNSUPPORTED when no librccl.so can be loaded.
+ * ---------------------------------------------------------------------------------- */
+#define VBQ_COMM_ID_BYTES 128
+int vbq_comm_unique_id(void *h_id);
+int vbq_comm_init(void **comm, int32_t n_ranks, const void *h_id, int32_t rank);
+int vbq_allreduce_hist(void *comm, void *d_counts, int64_t n, int32_t counts_are_i32, void *stream);
+int vbq_comm_destroy(void *comm);
+
+/* ----------------------------------------------------------------------------------
  * Comparison quantizers (img-compression/quantizer.py:259-333).
  *   vbq_uniform_quantize_f32  I = clip(floor((x - min) / delta), 0, levels-1) in f32 (:280,295),
  *                             value = offset + delta * I (:297); I is returned as f32 like the

@@ -86,5 +86,14 @@ def test_argument_validation_of_the_newer_entry_points(built_lib):
     assert h.vbq_image_sqerr_u8(None, None, -1, 4, None, None) == -1
     assert h.vbq_pack_counts_3x21(None, -1, None, 1, None, None) == -1 and h.vbq_pack_counts_3x21(None, 0, None, 1, None, None) == 0
     assert h.vbq_pack_counts_3x21(None, 3, None, 0, None, None) == -1 and b"n_ranks" in h.vbq_last_error()
+    assert h.vbq_allreduce_hist(None, None, -1, 0, None) == -1 and h.vbq_allreduce_hist(None, None, 0, 0, None) == 0
+    assert h.vbq_allreduce_hist(None, None, 5, 1, None) == -1 and b"null pointer" in h.vbq_last_error()
+    assert h.vbq_comm_init(None, 2, None, 0) == -1 and h.vbq_comm_unique_id(None) == -1 and h.vbq_comm_destroy(None) == 0
+    assert h.vbq_level_counts_f32(None, None, 4, 1, 0, None, None, None, 1, 10, None, None, 0, None) == -1
+    assert h.vbq_quantize_rows_f32(None, None, 4, 1, 0, None, None, None, 1, 10, 0, None, None, None, None, 0, 3, 2, 0, None) == -1
+    assert b"row range" in h.vbq_last_error()
+    assert h.vbq_histogram_rows_u16(None, 4, 1, 0, 1, 10, None, 0, 0, 5, None) == -1 and b"row range" in h.vbq_last_error()
+    assert h.vbq_code_lengths_from_counts(None, 0, 3, None, 0, 0, None, None, None) == -1
+    assert h.vbq_index_max_u16(None, 0, None, None) == 0 and h.vbq_index_max_u16(None, 4, None, None) == -1
     assert h.vbq_downsample2_f64(None, 1, 0, 4, 1, None, None) == -1
     assert h.vbq_transpose_f32(None, 4, 4, None, None) == -1

@@ -16,6 +16,7 @@ ABI_VERSION = 2
 LAYOUT_BC, LAYOUT_CB, LAYOUT_BC_TO_CB = 0, 1, 2
 MODE_F32, MODE_F64_SCORE = 0, 1
 BMSHJ_PARAMS_PER_CHANNEL = 43
+COMM_ID_BYTES = 128
 
 # name -> (restype, argtypes); mirrors include/vbq.h one to one (tests/test_abi.py checks it)
 SIGNATURES = {
@@ -70,6 +71,10 @@ SIGNATURES = {
     "vbq_downsample2_f64": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "vbq_pack_counts_3x21": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "vbq_unpack_counts_3x21": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "vbq_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "vbq_comm_init": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_void_p, C.c_int32]),
+    "vbq_allreduce_hist": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
+    "vbq_comm_destroy": (C.c_int, [C.c_void_p]),
     "vbq_rans_encode_u16": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p]),
     "vbq_rans_decode_u16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p,

@@ -75,6 +75,53 @@ def entropy_models_from_local_counts(local_counts: torch.Tensor, N: int, add_n_s
     return raw, full
 
 
+class Communicator:
+    """The C-ABI's own RCCL communicator (vbq_comm_* / vbq_allreduce_hist, include/vbq.h): what a binder WITHOUT
+    torch.distributed uses for the histogram exchange.  Rank 0 creates the 128-byte id (`Communicator.unique_id()`)
+    and hands it to the other ranks by any means (a file, MPI, a socket); every rank then constructs the
+    communicator with its GPU current.  The torch.distributed path above remains what the Python host uses."""
+
+    def __init__(self, n_ranks: int, rank: int, unique_id: bytes):
+        import ctypes as C
+        from . import _lib
+        if len(unique_id) != _lib.COMM_ID_BYTES:
+            raise ValueError(f"unique_id must be {_lib.COMM_ID_BYTES} bytes")
+        self._h = _lib.lib()
+        self._comm = C.c_void_p()
+        buf = C.create_string_buffer(unique_id, _lib.COMM_ID_BYTES)
+        _lib.check(self._h.vbq_comm_init(C.byref(self._comm), int(n_ranks), buf, int(rank)), "vbq_comm_init")
+        self.n_ranks, self.rank = int(n_ranks), int(rank)
+
+    @staticmethod
+    def unique_id() -> bytes:
+        import ctypes as C
+        from . import _lib
+        buf = C.create_string_buffer(_lib.COMM_ID_BYTES)
+        _lib.check(_lib.lib().vbq_comm_unique_id(buf), "vbq_comm_unique_id")
+        return buf.raw
+
+    def all_reduce_(self, counts: torch.Tensor) -> torch.Tensor:
+        """In-place SUM of an int32 / int64 device tensor over the ranks, asynchronous on the current stream."""
+        from . import _lib, ops
+        if counts.dtype not in (torch.int32, torch.int64) or not counts.is_cuda or not counts.is_contiguous():
+            raise ValueError("counts must be a contiguous int32 / int64 device tensor")
+        _lib.check(self._h.vbq_allreduce_hist(self._comm, ops._ptr(counts), counts.numel(), int(counts.dtype == torch.int32),
+                                              ops._stream(counts)), "vbq_allreduce_hist")
+        return counts
+
+    def close(self):
+        from . import _lib
+        if self._comm:
+            _lib.check(self._h.vbq_comm_destroy(self._comm), "vbq_comm_destroy")
+            self._comm = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 PACKED_FIELD_LIMIT = 1 << 21
 
 

@@ -48,7 +48,7 @@ class EntropyModelBuild:
 
     def __init__(self, rows: int, n_ch: int, lambdas: Sequence[float], table_lm: torch.Tensor, *, N: int = 10,
                  add_n_smoothing=1, global_rows: Optional[int] = None, distributed: bool = False, group=None,
-                 n_chunks: Optional[int] = None, counts_dtype=None, keep_models: bool = True):
+                 level_group=None, n_chunks: Optional[int] = None, counts_dtype=None, keep_models: bool = True):
         self.rows, self.C, self.N = int(rows), int(n_ch), int(N)
         self.lambdas = [float(l) for l in lambdas]
         self.L = len(self.lambdas)
@@ -57,6 +57,9 @@ class EntropyModelBuild:
         self.dev = table_lm.device
         self.smooth = add_n_smoothing
         self.group = group
+        # The bit-length histogram's small all-reduce sits on the critical path (pass 2 needs its result); on its own
+        # communicator it does not queue behind the previous step's large, asynchronous rank-histogram all-reduce.
+        self.level_group = level_group if level_group is not None else group
         self.global_rows = int(global_rows if global_rows is not None else rows)
         # distributed: rows are sharded over the ranks of `group`; the two histograms are summed over them
         self.world = torch.distributed.get_world_size(group) if distributed else 1
@@ -65,7 +68,10 @@ class EntropyModelBuild:
             counts_dtype = torch.int32 if self.global_rows < 2 ** 31 else torch.int64
         self.idx = torch.empty((L, C, self.rows), dtype=torch.uint16, device=self.dev)
         self.level_counts = torch.zeros((L, C, N1), dtype=torch.int64, device=self.dev)
-        self.counts = torch.zeros((L, C, T), dtype=counts_dtype, device=self.dev)
+        # two rank-histogram buffers when sharded: step i's all-reduce runs while step i+1 fills the other one
+        self._counts2 = [torch.zeros((L, C, T), dtype=counts_dtype, device=self.dev) for _ in range(2 if self.world > 1 else 1)]
+        self._slot = 0
+        self.counts = self._counts2[0]
         self.ws = torch.empty(ops._lib.lib().vbq_quantize_workspace_bytes(C, L, N), dtype=torch.uint8, device=self.dev)
         lut1 = _entropy.neg_log2_lut(self.global_rows, N1, add_n_smoothing, max_entries=max(1 << 20, 4 * L * C * N1))
         lut2 = _entropy.neg_log2_lut(self.global_rows, T, add_n_smoothing, max_entries=max(1 << 20, L * C * T)) if keep_models else None
@@ -84,13 +90,13 @@ class EntropyModelBuild:
         self.k1_workgroups_per_cu = 4  # of 5 that fit: the fifth's LDS and wave slots are K2's while they overlap
         self.side = torch.cuda.Stream(device=self.dev) if len(self.chunks) > 1 else None
         self._events = [torch.cuda.Event() for _ in self.chunks] if self.side is not None else []
-        self.reducer = None
-        self.work = None
+        self.reducers = [None, None]
+        self.works = [None, None]
         self.timers = None             # bench.py: callable(name, phase) recording an event on the current stream
         self.collectives = True        # bench.py switches them off to measure what they cost
         if self.world > 1 and counts_dtype == torch.int32:
             from .dist import CountsAllReduce
-            self.reducer = CountsAllReduce(L * C * T, self.dev, max_global_count=self.global_rows, group=group)
+            self.reducers = [CountsAllReduce(L * C * T, self.dev, max_global_count=self.global_rows, group=group) for _ in range(2)]
 
     # ---------------------------------------------------------------- stages
     def pass1(self, mu_cb, sg_cb, level_len=None):
@@ -101,7 +107,7 @@ class EntropyModelBuild:
                          out=self.level_counts, workspace=self.ws)
         self._t("k1h", 1)
         if self.world > 1 and self.collectives:
-            torch.distributed.all_reduce(self.level_counts, group=self.group)
+            torch.distributed.all_reduce(self.level_counts, group=self.level_group)
         return self.level_counts
 
     def _t(self, name, phase):
@@ -124,8 +130,11 @@ class EntropyModelBuild:
         return self.level_len, self.raw_models
 
     def pass2(self, mu_cb, sg_cb, level_len):
-        """quantizer.py:119-140: indices and their per-(lambda, channel) histogram, K2 one chunk behind K1."""
-        self.wait()
+        """quantizer.py:119-140: indices and their per-(lambda, channel) histogram."""
+        if self.world > 1:
+            self._slot ^= 1
+            self.counts = self._counts2[self._slot]
+        self.wait(self._slot)                 # the all-reduce that last used this buffer
         self.counts.zero_()
         main = torch.cuda.current_stream(self.dev)
         if self.side is None:
@@ -151,23 +160,28 @@ class EntropyModelBuild:
                     self._t("k2", 1)
             main.wait_stream(self.side)
         if self.world > 1 and self.collectives:
-            if self.reducer is not None:
-                self.work = self.reducer.start(self.counts)
+            if self.reducers[self._slot] is not None:
+                self.works[self._slot] = self.reducers[self._slot].start(self.counts)
             else:
-                self.work = torch.distributed.all_reduce(self.counts, group=self.group, async_op=True)
+                self.works[self._slot] = torch.distributed.all_reduce(self.counts, group=self.group, async_op=True)
         return self.idx, self.counts
 
-    def wait(self):
+    @property
+    def reducer(self):
+        return self.reducers[self._slot]
+
+    def wait(self, slot=None):
         """The rank histogram's all-reduce (asynchronous, overlapping whatever was enqueued after pass2) is complete
-        for the compute stream after this."""
-        if self.work is not None:
-            self.work.wait()
-            self.work = None
+        for the compute stream after this (slot None: both buffers)."""
+        for s in ((0, 1) if slot is None else (slot,)):
+            if self.works[s] is not None:
+                self.works[s].wait()
+                self.works[s] = None
 
     def finish_models(self):
         """quantizer.py:141-146 -> f32 [L, C, T] on the device (table form), or None when the caller must take the
         counts to the host (entropy.neg_log2_freq)."""
-        self.wait()
+        self.wait(self._slot)
         if self.lut2 is None:
             return None
         ops._lib.check(ops._lib.lib().vbq_code_lengths_from_counts(
