@@ -221,6 +221,14 @@ int vbq_index_max_u16(const uint16_t *d_idx, int64_t n, uint32_t *d_max, void *s
 int vbq_moments_f32(const float *d_x, int64_t n_rows, int32_t n_ch, int32_t layout,
                     double *d_out /* [n_ch][2] */, void *stream);
 
+/* The notebook's moment in NumPy's own float32 order: d_out[0] = np.sum(x.ravel()**2) bit for bit (blocks of 8192
+ * elements, pairwise inside a block, block results chained; see vbq_hist.hip).  Replaces the reduction inside
+ * empirical_std = np.sqrt(np.mean(vecs_u.ravel()**2)) (ipynb:374); the caller divides by n and takes the root in
+ * float32.  d_x 16-byte aligned; workspace: vbq_numpy_sum_sq_workspace_bytes(n) bytes of device memory. */
+size_t vbq_numpy_sum_sq_workspace_bytes(int64_t n);
+int vbq_numpy_sum_sq_f32(const float *d_x, int64_t n, float *d_out, void *d_workspace, size_t workspace_bytes,
+                         void *stream);
+
 /* ----------------------------------------------------------------------------------
  * Table lookup by rank index: out[l][e] = tab[(l)][c(e)][idx[l][e]].  Replaces
  *   tf.gather(entropy_model, I, batch_dims=1)            quantizer.py:226-228

@@ -89,6 +89,15 @@ def moments(x, n_ch, layout=0):
     return out
 
 
+def numpy_sum_sq_f32(x):
+    """np.sum(x.ravel()**2) for float32 x in NumPy's own (pairwise, float32) order -> np.float32."""
+    x = np.ascontiguousarray(x, np.float32).ravel()
+    out = C.c_float(0)
+    r = lib().vbq_oracle_numpy_sum_sq_f32(_p(x), C.c_int64(x.size), C.byref(out))
+    assert r == 0
+    return np.float32(out.value)
+
+
 def rans_encode(idx, freq, seg):
     """idx u16 [S, n], freq u16 [S, T] -> (words u16 [S, nseg, seg+2], sizes u32 [S, nseg])."""
     idx = np.ascontiguousarray(idx, np.uint16)

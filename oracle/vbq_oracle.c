@@ -177,6 +177,41 @@ int vbq_oracle_moments(const float *x, int64_t n_rows, int32_t n_ch, int32_t lay
     return 0;
 }
 
+/* NumPy's float32 pairwise summation (numpy/core/src/umath/loops_utils.h.src, FLOAT_pairwise_sum: unrolled blocks of
+ * at most 128 elements with 8 accumulators, recursive halving on multiples of 8 above that) applied to x[i]*x[i] with
+ * the product rounded to float32 first, in blocks of 8192: np.sum(x.ravel()**2) for a contiguous float32 x -- the reduction behind the
+ * notebook's empirical_std = np.sqrt(np.mean(vecs_u.ravel()**2)) (ipynb:374).  Pinned against NumPy itself in
+ * tests/test_oracle_c.py (NumPy is what the reference runs). */
+static float pw_sq(const float *a, int64_t n) {
+    if (n < 8) {
+        float res = 0.0f;
+        for (int64_t i = 0; i < n; ++i) res += a[i] * a[i];
+        return res;
+    }
+    if (n <= 128) {
+        float r[8];
+        for (int j = 0; j < 8; ++j) r[j] = a[j] * a[j];
+        int64_t i;
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; ++j) r[j] += a[i + j] * a[i + j];
+        float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; ++i) res += a[i] * a[i];
+        return res;
+    }
+    int64_t n2 = n / 2;
+    n2 -= n2 % 8;
+    return pw_sq(a, n2) + pw_sq(a + n2, n - n2);
+}
+
+/* The reduction loop hands the pairwise routine at most 8192 elements at a time (NumPy's iterator buffer size) and
+ * adds the block results one after the other: acc = fl(acc + pairwise(block)). */
+int vbq_oracle_numpy_sum_sq_f32(const float *x, int64_t n, float *out) {
+    float acc = 0.0f;
+    for (int64_t i = 0; i < n; i += 8192) acc += pw_sq(x + i, n - i < 8192 ? n - i : 8192);
+    *out = acc;
+    return 0;
+}
+
 int vbq_oracle_max_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

@@ -152,8 +152,8 @@ def g5_g6_g8():
     # G6: exhaustive search over all 2047 sorted code points, reference quantize_indep_dims, per row.
     rank_levels = O.levels_of_sorted_ranks(N)
     lens_sorted = np.repeat(rank_levels[None, :], C, axis=0).astype(np.float32)
-    rows = np.arange(0, 48)
-    lam_sel = [0, 9, 16, 24, 31]
+    rows = np.arange(0, B)                   # every row (edge rows included) x every lambda: 24 576 exhaustive solves
+    lam_sel = list(range(len(lam32)))
     zh = np.empty((len(lam_sel), rows.shape[0], C), np.float32)
     nb = np.empty((len(lam_sel), rows.shape[0], C), np.float32)
     for a, li in enumerate(lam_sel):
@@ -191,6 +191,84 @@ def g7():
     save("g7_notebook.npz", means=vecs_u, stds=stds_u, empirical_std=np.asarray(ns["empirical_std"]),
          codepoints=ns["codepoints"], lengths=ns["lengths"], betas=np.array(betas),
          optima=np.stack(outs), entropy=np.array(ents))
+
+
+# ---------------------------------------------------------------- G12 (duplicate code points, inputs beyond the table)
+def g12():
+    """The reference's exhaustive solver (utils.quantize_indep_dims over all 2047 sorted points) on what the restated
+    TF glue is most likely to get wrong: (a) tables whose float32 cast REPEATS code points (a narrow prior far from
+    zero: hundreds of equal neighbours, across and within bit levels -- the canonical-qidx case of quantizer.py:135);
+    (b) inputs beyond both ends of the table by many different margins and just inside the outermost interval of every
+    bit level (the edge padding of the per-level grids, quantizer.py:54-57,75-76).  Algorithm 1's 21 candidates must
+    still contain the exhaustive optimum, with the same value and the same bit length."""
+    rng = np.random.default_rng(112)
+    C = 3
+    ch_mean = np.array([100.0, 1000.0, 0.3])
+    ch_std = np.array([1e-3, 1e-3, 1.7])
+    orc = O.ChannelwiseOracle(C, N)
+    orc.build_code_points(O.factored_gaussian_icdf(ch_mean, ch_std))
+    srt = orc.by_channel                                                        # C x T sorted (== rank order)
+    n_dup = [int(T_ - np.unique(srt[c]).size) for c, T_ in enumerate([srt.shape[1]] * C)]
+    assert n_dup[0] > 50 and n_dup[1] > 1500 and n_dup[2] == 0, n_dup
+    rows = []
+    for c in range(C):
+        t = srt[c]
+        span = float(t[-1] - t[0]) if t[-1] > t[0] else 1.0
+        col = list(ch_mean[c] + ch_std[c] * rng.normal(0, 1.5, 60))             # ordinary inputs
+        col += list(t[rng.integers(0, t.size, 20)])                             # exact hits (repeated values included)
+        for k in (1e-7, 1e-3, 0.01, 0.1, 0.5, 1, 3, 10, 100):                   # beyond both ends
+            col += [t[-1] + k * span, t[0] - k * span]
+        for n in range(1, N + 1):                                               # outermost interval of every level
+            lv = orc.all_code_points[c, 2 ** n - 1: 2 ** (n + 1) - 1]
+            col += [0.5 * (float(lv[-1]) + float(t[-1])), 0.5 * (float(lv[0]) + float(t[0])),
+                    np.nextafter(lv[-1], np.float32(np.inf)), np.nextafter(lv[0], np.float32(-np.inf))]
+        rows.append(np.array(col, dtype=np.float32))
+    B = min(len(r) for r in rows)
+    mu = np.stack([r[:B] for r in rows], axis=1)                                # B x C
+    sigma = (ch_std[None, :] * np.exp(rng.normal(-2, 1.0, (B, C)))).astype(np.float32)
+    lens_sorted = np.repeat(O.levels_of_sorted_ranks(N)[None, :], C, axis=0).astype(np.float32)
+    lam32 = [np.float32(l) for l in LAMBDAS32]
+    zh = np.empty((len(lam32), B, C), np.float32)
+    nb = np.empty((len(lam32), B, C), np.float32)
+    for a, lamb in enumerate(lam32):
+        for r in range(B):
+            f_row = ref_utils.curry_normal_logpdf(loc=mu[r], scale=sigma[r], ignore_const=True, backend=object())
+            z, n_ = ref_utils.quantize_indep_dims(mu[r], srt, lens_sorted, f_row, lamb, backend=np)
+            zh[a, r], nb[a, r] = z, n_
+    save("g12_duplicates_edges.npz", ch_mean=ch_mean, ch_std=ch_std, all_code_points=orc.all_code_points, mu=mu,
+         sigma=sigma, lambdas=LAMBDAS32, zhat=zh, bits=nb.astype(np.int32), n_duplicates=np.array(n_dup))
+
+
+# ---------------------------------------------------------------- G13 (the notebook's chain, end to end)
+def g13():
+    """Cells 25, 26, 28, 29 of the notebook run as a CHAIN on one seeded embedding: the float32 moment (np.mean of
+    21 000 squares: more than two of NumPy's 8192-element summation blocks plus a ragged one) -> the code book built from
+    THAT number -> compress_coordinates -> empirical_entropy.  g7 feeds the stages separately; this fixes what the
+    notebook actually computes when one stage's rounding feeds the next."""
+    nb_path = os.path.join(REF, "word-embeddings", "compress-trained-word-embeddings.ipynb")
+    cells = json.load(open(nb_path))["cells"]
+    src = {i: "".join(c["source"]) for i, c in enumerate(cells) if c["cell_type"] == "code"}
+    rng = np.random.default_rng(113)
+    V, D = 3000, 7
+    vecs_u = rng.normal(-0.0799, 1.2329, (V, D)).astype(np.float32)
+    stds_u = np.clip(np.exp(rng.normal(-2, 0.7, (V, D))), 1e-4, 10).astype(np.float32)
+    import collections
+    import scipy.stats
+    ns = dict(np=np, scipy=scipy, Counter=collections.Counter, vecs_u=vecs_u, stds_u=stds_u, print=lambda *a, **k: None)
+    for cid, must in ((25, "empirical_std"), (26, "codepoints_and_lengths"), (28, "def compress_coordinates"),
+                      (29, "def empirical_entropy")):
+        assert must in src[cid], (cid, src[cid][:80])
+        exec(src[cid], ns)
+    assert np.asarray(ns["empirical_std"]).dtype == np.float32
+    betas = [0.02, 0.6, 17.0, 2500.0]
+    outs, ents = [], []
+    for beta in betas:
+        opt, _ = ns["compress_coordinates"](vecs_u, stds_u, float(beta))
+        outs.append(opt.copy())
+        ents.append(ns["empirical_entropy"](opt))
+    save("g13_notebook_chain.npz", means=vecs_u, stds=stds_u, empirical_std=np.asarray(ns["empirical_std"]),
+         codepoints=ns["codepoints"], lengths=ns["lengths"], betas=np.array(betas), optima=np.stack(outs),
+         entropy=np.array(ents))
 
 
 # ---------------------------------------------------------------- G9 (baseline quantizers, SURVEY 8f row f3)
@@ -277,6 +355,8 @@ if __name__ == "__main__":
     g4()
     g5_g6_g8()
     g7()
+    g12()
+    g13()
     g9()
     g10()
     g11()

@@ -127,8 +127,8 @@ def test_embeddings_golden(golden):
     from vbq_amd import embeddings as E
     g = golden("g7_notebook.npz")
     es = E.empirical_std(g["means"])
-    assert es.dtype == np.float32 and abs(float(es) - float(g["empirical_std"])) <= 1e-6 * float(g["empirical_std"])
-    pts, lens = E.make_code_book(g["empirical_std"], 10)
+    assert es.dtype == np.float32 and es == g["empirical_std"]            # NumPy's float32 summation order, on the GPU
+    pts, lens = E.make_code_book(es, 10)
     assert np.array_equal(pts, g["codepoints"]) and np.array_equal(lens, g["lengths"])
     for i, beta in enumerate(g["betas"]):
         out = E.compress_coordinates(g["means"], g["stds"], float(beta), bitlengths=lens, codepoints=pts)
@@ -410,3 +410,59 @@ def test_quantizer_class_at_eleven_bits():
     for l in lambs:
         assert np.array_equal(out["Z_hat"][l].reshape(-1, C), want["Z_hat"][l])
         assert np.array_equal(out["num_bits"][l].reshape(-1, C), want["num_bits"][l])
+
+
+def test_g12_duplicates_and_edges_on_gpu(golden):
+    """g12 (reference exhaustive solver on tables with repeated float32 code points and on inputs beyond / at the rim of
+    every level's grid): K1's Z_hat / bit lengths, in both layouts, the counting kernel, and the quantizer class with
+    its canonical qidx (quantizer.py:135,223)."""
+    from vbq_amd import ChannelwisePriorCDFQuantizer, ops, priors
+    g = golden("g12_duplicates_edges.npz")
+    lam = [float(l) for l in g["lambdas"]]
+    tab = torch.from_numpy(g["all_code_points"]).cuda()
+    mu, sg = torch.from_numpy(g["mu"]).cuda(), torch.from_numpy(g["sigma"]).cuda()
+    for layout, m, s in (("bc", mu, sg), ("cb", mu.t().contiguous(), sg.t().contiguous())):
+        idx, zh, bt = ops.quantize(m, s, tab, lam, N=N, layout=layout, want_zhat=True, want_bits=True)
+        zh, bt = zh.cpu().numpy(), bt.cpu().numpy()
+        if layout == "cb":
+            zh, bt = zh.transpose(0, 2, 1), bt.transpose(0, 2, 1)
+        assert np.array_equal(zh, g["zhat"]) and np.array_equal(bt.astype(np.int32), g["bits"])
+    lc = ops.level_counts(mu.t().contiguous(), sg.t().contiguous(), tab, lam, N=N, layout="cb").cpu().numpy()
+    want = np.stack([[np.bincount(g["bits"][l][:, c], minlength=N + 1) for c in range(mu.shape[1])] for l in range(len(lam))])
+    assert np.array_equal(lc, want)
+    q = ChannelwisePriorCDFQuantizer(mu.shape[1], N)
+    q.build_code_points(priors.FactoredGaussianPrior(g["ch_mean"], g["ch_std"]))
+    assert np.array_equal(q.all_code_points, g["all_code_points"]) and not q._strict
+    Zd, Bd = q.compress_batch_channel_latents(g["mu"], g["sigma"], lam)
+    for i, l in enumerate(lam):
+        assert np.array_equal(Zd[l], g["zhat"][i]) and np.array_equal(Bd[l], g["bits"][i])
+
+
+def test_g13_notebook_chain_on_gpu(golden):
+    """The notebook's chain as it runs (ipynb:373-390, 429-455): moment on the GPU in NumPy's float32 order -> code book
+    from THAT number -> K1n -> K2 entropy; every stage equal to what the notebook's cells produced."""
+    from vbq_amd import embeddings as E
+    g = golden("g13_notebook_chain.npz")
+    es = E.empirical_std(g["means"])
+    assert es.dtype == np.float32 and es == g["empirical_std"]
+    assert abs(float(E.empirical_std(g["means"], exact=False)) - float(es)) <= 1e-6 * float(es)
+    pts, lens = E.make_code_book(es, 10)
+    assert np.array_equal(pts, g["codepoints"]) and np.array_equal(lens, g["lengths"])
+    for i, beta in enumerate(g["betas"]):
+        out = E.compress_coordinates(g["means"], g["stds"], float(beta), bitlengths=lens, codepoints=pts)
+        assert out.dtype == np.float32 and np.array_equal(out, g["optima"][i])
+        assert E.empirical_entropy(out) == pytest.approx(g["entropy"][i], rel=1e-12)
+
+
+@pytest.mark.parametrize("n", [0, 1, 7, 8, 100, 129, 8191, 8192, 8193, 3 * 8192, 100_000, 1_000_003, 10_000_000])
+def test_numpy_order_moment(n):
+    """vbq_numpy_sum_sq_f32 against the C restatement of NumPy's summation order (pinned to np.sum on the CPU side)
+    and, since NumPy is at hand, against np.sum itself."""
+    from oracle import c_oracle as CO
+    from vbq_amd import ops
+    rng = np.random.default_rng(n)
+    x = rng.normal(-0.0799, 1.2329, n).astype(np.float32)
+    got = np.float32(ops.numpy_sum_sq(torch.from_numpy(x).cuda()).cpu().numpy()[0])
+    assert got == CO.numpy_sum_sq_f32(x)
+    if n:
+        assert got == np.sum(x ** 2)

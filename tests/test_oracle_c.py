@@ -80,3 +80,19 @@ def test_c_matches_numpy_oracle_on_random_tables():
     Z, bits = orc.compress_batch(mu, sg, [np.float32(l) for l in lam])
     idx, zh, bt = CO.quantize(mu, sg, orc.all_code_points, lam, N=N, want_zhat=True, want_bits=True)
     assert np.array_equal(zh, Z) and np.array_equal(bt.astype(np.int32), bits)
+
+
+def test_numpy_pairwise_sum_is_what_numpy_does():
+    """The notebook's moment (ipynb:374) is np.mean of a 1-D float32 array: NumPy's pairwise float32 summation.  The C
+    restatement of that order must reproduce np.sum bit for bit on every size class (below 8, one block, ragged blocks,
+    deep recursion) -- NumPy itself, the library the reference runs on, is the pin here."""
+    rng = np.random.default_rng(8)
+    sizes = [0, 1, 7, 8, 9, 127, 128, 129, 255, 256, 257, 1000, 1023, 1024, 1025, 3001 * 5, 250 * 12, 99991, 100000,
+             1 << 20, (1 << 20) + 13, 10_000_000]
+    for n in sizes:
+        x = rng.normal(-0.0799, 1.2329, n).astype(np.float32)
+        want = np.sum(x ** 2) if n else np.float32(0)
+        assert want.dtype == np.float32
+        assert CO.numpy_sum_sq_f32(x) == want, n
+        if n:
+            assert np.sqrt(np.float32(CO.numpy_sum_sq_f32(x) / np.float32(n))) == np.sqrt(np.mean(x.ravel() ** 2))

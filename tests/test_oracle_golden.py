@@ -3,6 +3,7 @@
 import numpy as np
 from scipy.stats import norm
 
+from oracle import c_oracle as CO
 from oracle import vbq_oracle as O
 
 N = 10
@@ -232,3 +233,45 @@ def test_g11_image_metrics(golden):
         assert np.array_equal(o.image_mse(x, y), g[f"{k}_mse"])
         assert np.array_equal(o.image_psnr(x, y), g[f"{k}_psnr"])
         np.testing.assert_allclose(o.ms_ssim(x, y), g[f"{k}_msssim"], rtol=1e-9, atol=0)
+
+
+def test_g12_duplicates_and_edges(golden):
+    """Reference exhaustive solves on tables with repeated float32 code points and on inputs beyond / at the rim of
+    every level's grid: the restated Algorithm-1 glue (per-level searchsorted on padded grids, 21 candidates) and the
+    C oracle's rank formulation must return the same value and the same bit length."""
+    g = golden("g12_duplicates_edges.npz")
+    C = g["mu"].shape[1]
+    orc = O.ChannelwiseOracle(C, N)
+    orc.build_code_points(O.factored_gaussian_icdf(g["ch_mean"], g["ch_std"]))
+    assert np.array_equal(orc.all_code_points, g["all_code_points"])
+    assert list(g["n_duplicates"]) == [T_ - np.unique(r).size for r, T_ in ((r, r.size) for r in orc.by_channel)]
+    assert g["n_duplicates"][1] > 1500                                   # the table really is mostly repeats
+    lam = [np.float32(l) for l in g["lambdas"]]
+    Z, bits = orc.compress_batch(g["mu"], g["sigma"], lam, mode="f32")
+    assert np.array_equal(Z, g["zhat"]) and np.array_equal(bits, g["bits"])
+    idx = CO.quantize(g["mu"], g["sigma"], g["all_code_points"], list(g["lambdas"]), N=N)         # [L, B, C]
+    lev = O.levels_of_sorted_ranks(N)
+    for l in range(len(lam)):
+        assert np.array_equal(np.take_along_axis(orc.by_channel, idx[l].T.astype(np.int64), axis=1).T, g["zhat"][l])
+        assert np.array_equal(lev[idx[l]], g["bits"][l])
+    # canonical qidx (quantizer.py:135): the first sorted position of the value, whatever rank the solver reports
+    q = O.qidx_lookup(orc.by_channel, g["zhat"][5])
+    assert np.array_equal(np.take_along_axis(orc.by_channel, q, axis=1), g["zhat"][5].T)
+    assert np.all(q <= idx[5].T)
+
+
+def test_g13_notebook_chain(golden):
+    """The notebook's stages chained: NumPy float32 moment (restated in C, block by block) -> code book from that very
+    number -> brute-force compress_coordinates -> entropy."""
+    g = golden("g13_notebook_chain.npz")
+    means, stds = g["means"], g["stds"]
+    s = CO.numpy_sum_sq_f32(means)
+    assert s == np.sum(means.ravel() ** 2)
+    es = np.sqrt(np.float32(float(s) / means.size))
+    assert es.dtype == np.float32 and es == g["empirical_std"] == O.empirical_std(means)
+    pts, lens = O.notebook_code_book(es, 10)
+    assert np.array_equal(pts, g["codepoints"]) and np.array_equal(lens, g["lengths"])
+    for i, beta in enumerate(g["betas"]):
+        val, _ = CO.compress_coordinates(means, stds, float(beta), pts, lens, threads=4)
+        assert np.array_equal(val, g["optima"][i])
+        assert O.empirical_entropy(val) == g["entropy"][i]

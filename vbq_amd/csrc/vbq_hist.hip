@@ -572,6 +572,137 @@ extern "C" int vbq_index_max_u16(const uint16_t *d_idx, int64_t n, uint32_t *d_m
     return VBQ_OK;
 }
 
+// ---------------------------------------------------------------------------- the notebook's moment, in NumPy's order
+// empirical_std = np.sqrt(np.mean(vecs_u.ravel()**2)) (ipynb:374) is a float32 reduction, and float32 sums depend on
+// their order.  NumPy's order: the reduce loop hands its pairwise routine blocks of 8192 elements (the iterator's
+// buffer) and accumulates the block results one after the other; inside a block, halves are split on multiples of 8
+// down to runs of <= 128 elements, which are summed with 8 interleaved accumulators combined as
+// ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) (loops_utils.h.src, *_pairwise_sum).  Reproduced here operation for operation:
+// a full block is 64 runs of 128 -> one workgroup; the ragged last block and the chain over the block sums run on one
+// thread out of LDS.  oracle/vbq_oracle.c restates the same order in C and is pinned against np.sum.
+namespace vbq {
+namespace {
+constexpr int kNpBlock = 8192;
+constexpr int kNpRunStride = 136;      // 128 + 8 words: the 64 runs of a block start on different LDS banks
+
+__global__ void __launch_bounds__(256)
+k_np_block_sums_sq(const float *__restrict__ x, float *__restrict__ block_sums) {
+    __shared__ float sq[64 * kNpRunStride];
+    __shared__ float racc[512];
+    __shared__ float leaf[64];
+    const float *src = x + (long)blockIdx.x * kNpBlock;
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int e = (k * 256 + t) * 4;                      // element within the block; 4 | 128: one run per float4
+        const float4 v = *reinterpret_cast<const float4 *>(src + e);
+        float *d = sq + (e >> 7) * kNpRunStride + (e & 127);
+        d[0] = __fmul_rn(v.x, v.x); d[1] = __fmul_rn(v.y, v.y); d[2] = __fmul_rn(v.z, v.z); d[3] = __fmul_rn(v.w, v.w);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int p = t + 256 * h, run = p >> 3, j = p & 7;
+        const float *a = sq + run * kNpRunStride + j;
+        float r = a[0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) r = __fadd_rn(r, a[8 * i]);
+        racc[p] = r;
+    }
+    __syncthreads();
+    if (t < 64) {
+        const float *r = racc + 8 * t;
+        leaf[t] = __fadd_rn(__fadd_rn(__fadd_rn(r[0], r[1]), __fadd_rn(r[2], r[3])),
+                            __fadd_rn(__fadd_rn(r[4], r[5]), __fadd_rn(r[6], r[7])));
+    }
+    __syncthreads();
+    for (int s2 = 1; s2 < 64; s2 <<= 1) {
+        if (t < 64 && (t & (2 * s2 - 1)) == 0) leaf[t] = __fadd_rn(leaf[t], leaf[t + s2]);
+        __syncthreads();
+    }
+    if (t == 0) block_sums[blockIdx.x] = leaf[0];
+}
+
+// pairwise sum of n <= 8192 ready-made squares (one thread; recursion depth <= 7)
+__device__ __noinline__ float np_pairwise(const float *a, int n) {
+    if (n < 8) {
+        float res = 0.0f;
+        for (int i = 0; i < n; ++i) res = __fadd_rn(res, a[i]);
+        return res;
+    }
+    if (n <= 128) {
+        float r[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = a[j];
+        int i;
+        for (i = 8; i < n - (n % 8); i += 8)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r[j] = __fadd_rn(r[j], a[i + j]);
+        float res = __fadd_rn(__fadd_rn(__fadd_rn(r[0], r[1]), __fadd_rn(r[2], r[3])),
+                              __fadd_rn(__fadd_rn(r[4], r[5]), __fadd_rn(r[6], r[7])));
+        for (; i < n; ++i) res = __fadd_rn(res, a[i]);
+        return res;
+    }
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    const float lo = np_pairwise(a, n2);
+    return __fadd_rn(lo, np_pairwise(a + n2, n - n2));
+}
+
+__global__ void __launch_bounds__(256)
+k_np_finish(const float *__restrict__ x, long n, const float *__restrict__ block_sums, float *__restrict__ out) {
+    __shared__ float buf[kNpBlock];
+    const long nfull = n / kNpBlock;
+    float acc = 0.0f;
+    for (long b0 = 0; b0 < nfull; b0 += kNpBlock) {           // the chain over the block sums, 8192 at a time out of LDS
+        const int m = (int)(nfull - b0 < kNpBlock ? nfull - b0 : kNpBlock);
+        for (int i = threadIdx.x; i < m; i += blockDim.x) buf[i] = block_sums[b0 + i];
+        __syncthreads();
+        if (threadIdx.x == 0)
+            for (int i = 0; i < m; ++i) acc = __fadd_rn(acc, buf[i]);
+        __syncthreads();
+    }
+    const int tail = (int)(n - nfull * kNpBlock);
+    if (tail > 0) {
+        for (int i = threadIdx.x; i < tail; i += blockDim.x) {
+            const float v = x[nfull * kNpBlock + i];
+            buf[i] = __fmul_rn(v, v);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) acc = __fadd_rn(acc, np_pairwise(buf, tail));
+    }
+    if (threadIdx.x == 0) out[0] = acc;
+}
+}  // namespace
+}  // namespace vbq
+
+extern "C" size_t vbq_numpy_sum_sq_workspace_bytes(int64_t n) {
+    return n <= 0 ? 0 : (size_t)(n / vbq::kNpBlock + 1) * sizeof(float);
+}
+
+extern "C" int vbq_numpy_sum_sq_f32(const float *d_x, int64_t n, float *d_out, void *d_workspace, size_t workspace_bytes,
+                                    void *stream) {
+    using namespace vbq;
+    VBQ_REQUIRE(n >= 0 && d_out, VBQ_ERR_INVALID_ARGUMENT, "vbq_numpy_sum_sq_f32: bad arguments");
+    VBQ_REQUIRE(n == 0 || d_x, VBQ_ERR_INVALID_ARGUMENT, "vbq_numpy_sum_sq_f32: null pointer");
+    VBQ_REQUIRE(n == 0 || (reinterpret_cast<uintptr_t>(d_x) & 15) == 0, VBQ_ERR_INVALID_ARGUMENT,
+                "vbq_numpy_sum_sq_f32: d_x must be 16-byte aligned");
+    const size_t need = vbq_numpy_sum_sq_workspace_bytes(n);
+    VBQ_REQUIRE(n == 0 || (d_workspace && workspace_bytes >= need), VBQ_ERR_WORKSPACE,
+                "vbq_numpy_sum_sq_f32: workspace of %zu bytes given, %zu needed", workspace_bytes, need);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int64_t nfull = n / kNpBlock;
+    VBQ_REQUIRE(nfull <= 0x7fffffffLL, VBQ_ERR_UNSUPPORTED, "vbq_numpy_sum_sq_f32: more than 2^44 elements");
+    float *bs = reinterpret_cast<float *>(d_workspace);
+    if (nfull > 0) {
+        hipLaunchKernelGGL(k_np_block_sums_sq, dim3((unsigned)nfull), dim3(256), 0, st, d_x, bs);
+        VBQ_CHECK_LAUNCH("np_block_sums");
+    }
+    hipLaunchKernelGGL(k_np_finish, dim3(1), dim3(256), 0, st, d_x, (long)n, bs, d_out);
+    VBQ_CHECK_LAUNCH("np_finish");
+    return VBQ_OK;
+}
+
 extern "C" int vbq_moments_f32(const float *d_x, int64_t n_rows, int32_t n_ch, int32_t layout, double *d_out,
                                void *stream) {
     using namespace vbq;

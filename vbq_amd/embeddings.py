@@ -30,10 +30,16 @@ def _dev(a, dtype=torch.float32):
     return t.to(_device(), dtype).contiguous()
 
 
-def empirical_std(vecs) -> np.float32:
-    """sqrt(mean(x**2)) (ipynb:374).  Sums are accumulated in f64 on the GPU (the notebook's f32
-    pairwise mean differs from this by rounding only; tolerance 1e-6 relative)."""
+def empirical_std(vecs, exact: bool = True) -> np.float32:
+    """np.sqrt(np.mean(vecs.ravel()**2)) (ipynb:374), float32.  exact=True reproduces NumPy's float32 summation order
+    on the GPU (vbq_numpy_sum_sq_f32), so the code book built from it is the notebook's bit for bit; exact=False is
+    the f64-accumulating moment kernel K3 (order-free, agrees to 1e-6 relative, a little faster)."""
     x = _dev(vecs).reshape(-1)
+    if exact:
+        s = np.float32(ops.numpy_sum_sq(x).cpu().numpy()[0])
+        # np.mean: the f32 sum divided by the count (a float64 division under NumPy 1.17's scalar rules, rounded back
+        # to f32 -- the same value as an f32 division whenever the count is a float32 number), then the root in f32
+        return np.sqrt(np.float32(float(s) / x.numel()))
     m = ops.moments(x)
     return np.float32(np.sqrt(float(m[0, 1].item()) / x.numel()))
 

@@ -260,6 +260,17 @@ def moments(x: torch.Tensor, *, layout="bc", out: Optional[torch.Tensor] = None)
     return out
 
 
+def numpy_sum_sq(x: torch.Tensor) -> torch.Tensor:
+    """vbq_numpy_sum_sq_f32: np.sum(x.ravel()**2) of a float32 tensor in NumPy's own summation order -> f32 [1] (device)."""
+    x = _dev(x, torch.float32, "x").reshape(-1)
+    out = torch.zeros(1, dtype=torch.float32, device=x.device)
+    h = _lib.lib()
+    wsb = h.vbq_numpy_sum_sq_workspace_bytes(x.numel())
+    ws = torch.empty(max(wsb, 4), dtype=torch.uint8, device=x.device)
+    check(h.vbq_numpy_sum_sq_f32(_ptr(x), x.numel(), _ptr(out), _ptr(ws), wsb, _stream(x)), "vbq_numpy_sum_sq_f32")
+    return out
+
+
 def gather(idx: torch.Tensor, tab: torch.Tensor, n_ch: int, *, N: int = 10, layout="bc", out_layout=None):
     """vbq_gather_f32: out[l][e] = tab[(l,) c(e), idx[l][e]].  tab: f32 [C, T] or [L, C, T] indexed by RANK.
     With out_layout != layout the result comes back transposed (e.g. idx [L, C, B] -> out [L, B, C])."""
