@@ -90,6 +90,60 @@ def test_level_counts_ties_and_edges(ops):
         assert np.array_equal(got.cpu().numpy(), want)
 
 
+def test_threshold_kernel_on_ties_and_odd_sweeps(ops):
+    """K1t (raw lengths, no per-lambda loop) on what its guard bands exist for: thresholds that sit exactly on sweep
+    points (lambda = (du_i - du_j) / (j - i) by construction), exact code-point hits and mid-points, inputs outside the
+    table, extreme sigmas; sweeps that are unsorted, short, randomly spaced; and sweeps it must hand to the dense kernel
+    (repeated values, two points in one bucket, more than 16 octaves)."""
+    rng = np.random.default_rng(21)
+    tab, _, _ = synth(rng, 4, 1)
+    t = np.sort(tab[0])
+    mids = (t[:-1] + t[1:]) * np.float32(0.5)
+    mu = np.concatenate([t, mids, [t[0] - 50, t[-1] + 50, 0.0], rng.normal(0, 1, 6000).astype(np.float32)]).astype(np.float32)
+    sg = np.concatenate([np.full(t.size + mids.size + 3, 1.0), np.exp(rng.normal(-2, 2.5, 6000))]).astype(np.float32)
+    sg[::7] = np.float32(0.99999994)
+    sg[5::11] = np.float32(2.0 ** -10)                               # du values that are exact multiples of powers of two
+    sweeps = [LAM32, LAM32[::-1], [LAM32[i] for i in rng.permutation(32)[:9]], [0.37], [2.0 ** k for k in range(-10, 9)],
+              [float(v) for v in np.sort(np.exp(rng.uniform(np.log(1e-3), np.log(1e3), 32)))],
+              [1.0, 1.0, 2.0],                                       # repeated value      -> dense kernel
+              [1.0, 1.0 + 2.0 ** -9, 4.0],                           # same bucket         -> dense kernel
+              [1e-9, 1.0, 1e9]]                                      # > 16 octaves        -> dense kernel
+    for lam in sweeps:
+        want = oracle_level_counts(mu[:, None], sg[:, None], tab, lam, None)
+        got = ops.level_counts(dev(mu), dev(sg), dev(tab), lam, N=N)
+        assert np.array_equal(got.cpu().numpy(), want), lam
+    # thresholds exactly on sweep points: pick lambda from the element's own cost differences
+    idx = ops.quantize(dev(mu[-6000:]), dev(sg[-6000:]), dev(tab), [0.5], N=N, want_zhat=True)[1].cpu().numpy()[0]
+    d = ((idx - mu[-6000:]) / sg[-6000:]) ** 2 * np.float32(0.5)
+    lam = sorted({float(np.float32(v)) for v in d[(d > 1e-3) & (d < 1e3)][:400:13]})
+    lam = [v for i, v in enumerate(lam) if i == 0 or v > lam[i - 1] * 1.02][:32]
+    want = oracle_level_counts(mu[:, None], sg[:, None], tab, lam, None)
+    assert np.array_equal(ops.level_counts(dev(mu), dev(sg), dev(tab), lam, N=N).cpu().numpy(), want)
+
+
+@pytest.mark.timeout(900)
+def test_threshold_kernel_guard_machinery():
+    """tools/stress_parity.py --levels: (0) as built, every window's histogram equals the oracle's; (1) with every sweep
+    point forced through the literal scan + correction it still does; (2) with the guard bands switched off wrong counts
+    appear on the same data -- the adversarial inputs do reach the near-tie cases and the bands are what keeps K1t exact."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "tools", "stress_parity.py"), "--levels", "--n", "400000", "--rounds", "4"]
+
+    def run(dbg):
+        env = dict(os.environ, VBQ_FAST_DEBUG=str(dbg))
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=800)
+        return r.returncode, r.stdout + r.stderr[-2000:]
+    rc0, out0 = run(0)
+    assert rc0 == 0, out0
+    rc1, out1 = run(1)
+    assert rc1 == 0, out1
+    rc2, out2 = run(2)
+    assert rc2 == 1, out2
+
+
 def test_level_counts_agrees_with_quantize_plus_histogram(ops):
     """Same counts as the two-kernel route (K1 indices -> K2 rank histogram -> sum over the ranks of a level)."""
     from vbq_amd import entropy

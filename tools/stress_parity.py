@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """Large randomized parity stress: HIP K1 (fast plane kernel) vs the C oracle, bit for bit.
-    python tools/stress_parity.py [--n 4000000] [--rounds 6]
+    python tools/stress_parity.py [--n 4000000] [--rounds 6] [--levels]
+--levels: the counting kernels instead (K1t thresholds for raw lengths, K1h dense for corrected ones): bit-length
+histograms of windows of 20 000 elements against np.bincount of the oracle's levels, with varied lambda sweeps
+(geometric, random spacing, unsorted, short) -- one wrong element shows up as two wrong counts.
 Covers raw and corrected (random) lengths, narrow / wide / duplicate tables, tiny and huge
 sigma, mu on and between code points, and the f64-score mode."""
 import argparse
@@ -48,11 +51,58 @@ def case(rng, kind, n):
     return tab, mu, sg, level_len
 
 
+def sweep(rng, r):
+    """Lambda sweeps for the counting stress: the bench's, randomly spaced ones, unsorted, short."""
+    if r % 4 == 0:
+        return LAM
+    L = int(rng.integers(1, 33))
+    lam = np.exp(rng.uniform(np.log(2e-4), np.log(4e3), L))
+    if r % 4 == 1:
+        lam = np.sort(lam)
+    if r % 4 == 3:
+        lam = 2.0 ** rng.integers(-12, 12, L).astype(np.float64)       # powers of two, repeats likely (dense fallback)
+    return [float(v) for v in lam]
+
+
+def levels_main(args):
+    from oracle import vbq_oracle as O
+    dev = torch.device("cuda")
+    rng = np.random.default_rng(777)
+    lev = O.levels_of_sorted_ranks(N)
+    W = 20_000
+    total = bad = 0
+    kinds = ["raw", "raw", "t", "dup", "corr", "raw"]
+    for r in range(args.rounds):
+        kind = kinds[r % len(kinds)]
+        tab, mu, sg, ll = case(rng, kind, args.n)
+        lam = sweep(rng, r) if kind != "corr" and kind != "dup" else LAM
+        if kind == "dup":
+            ll = None
+        want_idx = CO.quantize(mu, sg, tab, lam, N=N, level_len=ll, threads=CO.max_threads())[:, :, 0]
+        wl = lev[want_idx]                                                         # [L, n]
+        nb = 0
+        tabd = torch.from_numpy(tab).to(dev)
+        lld = None if ll is None else torch.from_numpy(ll).to(dev)
+        for s0 in range(0, args.n, W):
+            m, s_ = torch.from_numpy(mu[s0:s0 + W]).to(dev), torch.from_numpy(sg[s0:s0 + W]).to(dev)
+            got = ops.level_counts(m, s_, tabd, lam, N=N, level_len=lld).cpu().numpy()[:, 0, :]
+            want = np.stack([np.bincount(wl[l, s0:s0 + W], minlength=N + 1) for l in range(len(lam))])
+            nb += int(np.count_nonzero(got != want))
+        total += wl.size
+        bad += nb
+        print(f"round {r} [{kind:4s}, {len(lam):2d} lambdas] {wl.size:.3g} latents in windows of {W}: wrong counts {nb}", flush=True)
+    print(f"TOTAL {total:.4g} latents counted, {bad} mismatches")
+    sys.exit(1 if bad else 0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=4_000_000)
     ap.add_argument("--rounds", type=int, default=6)
+    ap.add_argument("--levels", action="store_true")
     args = ap.parse_args()
+    if args.levels:
+        return levels_main(args)
     dev = torch.device("cuda")
     rng = np.random.default_rng(2024)
     total = bad = 0

@@ -59,4 +59,10 @@ int launch_quant_fast(const float *mu, const float *sg, int64_t n_per_ch, int64_
                       float *out_bits, int64_t E, int vec_ok, const unsigned int *odd_pen,
                       unsigned long long *level_counts, int wg_per_cu, hipStream_t st);
 
+// K1t (vbq_quantize_fast.hip): first entropy-model pass without a per-lambda loop; N = 10, raw lengths.  Returns 1 when the
+// lambda sweep is not eligible (caller falls back to the dense counting kernel).
+int launch_level_counts_hull10(const float *mu, const float *sg, int64_t n_per_ch, int64_t ch_stride, int32_t n_ch,
+                               const float *table, const float *pen, const double *lam, int32_t L, int vec_ok,
+                               unsigned long long *level_counts, hipStream_t st);
+
 }  // namespace vbq

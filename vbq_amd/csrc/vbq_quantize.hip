@@ -387,6 +387,15 @@ int launch_quantize(const float *mu, const float *sg, int64_t n_rows, int32_t n_
             bool fast_ok = sizeof(PenT) == 4 && !force_plain_kernel();
             // (vbq_quantize_fast.hip: the equality mask needs every lambda*len >= 2^-39 for len >= 1)
             for (int i = 0; i < Lc; ++i) fast_ok = fast_ok && (lc.lam[i] >= 1.9e-12 && lc.lam[i] <= 1.8e19);
+            if constexpr (sizeof(PenT) == 4 && N == 10) {
+                // first entropy-model pass (raw lengths, levels only): thresholds instead of a per-lambda loop
+                if (fast_ok && lc_out && !len_c) {
+                    const int r = launch_level_counts_hull10(mu_r, sg_r, n_per_ch, ch_stride, n_ch, table, pen, lc.lam, Lc,
+                                                             vec_ok | (bc_to_cb ? 2 : 0), lc_out, st);
+                    if (r == VBQ_OK) continue;
+                    if (r < 0) return r;
+                }
+            }
             if constexpr (sizeof(PenT) == 4) {
                 if (fast_ok) {
                     const int r = launch_quant_fast<N>(mu_r, sg_r, n_per_ch, ch_stride, n_ch, table, pen, len_c, Lc, oi, oz, ob,

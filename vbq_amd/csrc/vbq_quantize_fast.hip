@@ -30,6 +30,7 @@
 //    A wave with any flagged lane re-solves those lanes for that lambda with the literal
 //    21-candidate scan (exact_rank_scan).  Both events have probability ~1e-6 per solve.
 #include <stdlib.h>
+#include <string.h>
 
 #include "vbq_common.h"
 
@@ -414,6 +415,250 @@ k_quant_fast(const float *__restrict__ mu, const float *__restrict__ sg, long n_
     }
 }
 
+
+// =====================================================================================================================
+// K1t: the first entropy-model pass (raw lengths, bit levels only) WITHOUT a per-lambda loop.
+//
+// With the raw lengths of quantizer.py:167-169 the cost of bit level n is a LINE in lambda, du_n + lambda * n, the same
+// 11 lines for every lambda of the sweep.  The winner as a function of lambda is therefore a staircase that only steps
+// down (the lower envelope of the lines, steeper lines first): it is described by 10 thresholds per element,
+//       T_n = sup { lambda : winner(lambda) > n } = max_{j > n} min_{i <= n} (du_i - du_j) / (j - i),   T_0 >= ... >= T_9,
+// and the level at lambda is #{ n : lambda < T_n }.  The histogram the pass wants, counts[l][n] = #{elements with level n
+// at lambda_l}, follows from the positions a_n = #{ l : lambda_(l) < T_n } of the thresholds in the SORTED sweep:
+//       #{ level > n at sorted index l } = #{ elements : a_n > l },
+// i.e. from ten 33-bin histograms of a_n -- 10 counter updates per element instead of 32 solves.
+//
+// Exactness.  The reference does not evaluate real-valued lines: it compares fl(du_n + fl(lambda32 * n)) and breaks ties
+// by candidate order.  Each rounded cost is within 2^-23 (1 + 2^-24) of the line's value, relatively; away from every
+// threshold the gap between the envelope and any other line is at least the distance |lambda - T| (slopes differ by >= 1),
+// so the rounded comparison and the real one agree whenever that distance exceeds 2^-22 of the envelope's height, which
+// level n's own line bounds from above.  Thresholds computed in f32 carry a relative error below 2^-22 (max / min commute
+// with the monotone map x -> x (1 +- d)).  Hence: the two sweep points next to every threshold are tested against the
+// guard band  2^-21 (du_n + lambda (n + 1));  a sweep point inside a band -- or any non-finite cost -- is re-solved for
+// that element with the literal 21-candidate scan and the histogram corrected by (+1 exact level, -1 predicted level).
+// About 3 in 10 000 (element, threshold) pairs take that path.  tests/test_gpu_twopass.py forces it (exact ties, equal
+// costs, thresholds on sweep points) and tools/stress_parity.py --levels compares 1e9+ solves with the C oracle.
+struct HullSweep {
+    float lam[32];          // the sweep rounded to f32, ascending
+    unsigned char perm[32]; // position of lam[l] in the caller's order
+    int L, key0, nkeys;     // keys = float bits >> 16 (sign, exponent, 7 mantissa bits); bucket b <-> key0 + b
+};
+constexpr int kHullKeys = 2048;         // 16 octaves of 128 buckets
+constexpr float kHullBig = 3.0e38f;
+
+template <int N>
+__global__ void __launch_bounds__(kFastThreads, 4)
+k_level_counts_hull(const float *__restrict__ mu, const float *__restrict__ sg, long n_per_ch, long ch_stride, int C,
+                    const float *__restrict__ table, const float *__restrict__ pen, HullSweep sw, int vec_ok,
+                    unsigned long long *__restrict__ level_counts, int dbg) {
+    constexpr int T = table_size(N);
+    constexpr int N1 = N + 1;
+    constexpr int NE = 2;
+    constexpr int PS = (N1 + 3) & ~3;
+    constexpr int LB = 33;                                    // positions 0..32
+    __shared__ float tb[T + 1];
+    __shared__ __align__(16) float penl[kMaxLambdaChunk * PS];
+    __shared__ unsigned char lut[kHullKeys];
+    __shared__ float sorted[36];                              // [0] = -big, [1 + l] = lam[l], then +big
+    __shared__ unsigned int H[N * LB * 16];                   // [n][a][16 words x 2 halves]
+    __shared__ int corr[kMaxLambdaChunk * N1];
+    __shared__ unsigned int n_valid;
+    const int c = blockIdx.y;
+    const int L = sw.L;
+    for (int i = threadIdx.x; i < T; i += blockDim.x) tb[i] = table[(long)c * T + i];
+    for (int i = threadIdx.x; i < L * PS; i += blockDim.x) {
+        const int l = i / PS, n = i - l * PS;
+        penl[i] = n < N1 ? pen[((long)l * C + c) * N1 + n] : 0.0f;
+    }
+    for (int i = threadIdx.x; i < N * LB * 16; i += blockDim.x) H[i] = 0;
+    for (int i = threadIdx.x; i < L * N1; i += blockDim.x) corr[i] = 0;
+    for (int b = threadIdx.x; b < kHullKeys; b += blockDim.x) {     // lut[b] = #{ l : lam[l] < lower edge of bucket b }
+        int cnt = 0;
+        for (int l = 0; l < L; ++l) cnt += ((int)(__float_as_uint(sw.lam[l]) >> 16) < sw.key0 + b) ? 1 : 0;
+        lut[b] = (unsigned char)cnt;
+    }
+    if (threadIdx.x < 36) {
+        const int l = (int)threadIdx.x - 1;
+        sorted[threadIdx.x] = l < 0 ? -kHullBig : (l < L ? sw.lam[l] : kHullBig);
+    }
+    if (threadIdx.x == 0) n_valid = 0;
+    __syncthreads();
+
+    const bool force_slow = dbg == 1, never_flag = dbg == 2;
+    const long base = (long)c * ch_stride;
+    const long nquads = (n_per_ch + NE - 1) / NE;
+    const char *tbb = reinterpret_cast<const char *>(tb);
+    const unsigned int lane = threadIdx.x & 63u;
+    const unsigned int inc = (lane & 16u) ? 0x10000u : 1u;
+    const unsigned int copy = lane & 15u;
+    unsigned int my_valid = 0;
+
+    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < nquads; q += (long)gridDim.x * blockDim.x) {
+        const long i0 = q * NE;
+        const bool full = (vec_ok & 1) && (i0 + NE <= n_per_ch);
+        float m4[NE], s4[NE];
+        if (vec_ok & 2) {
+#pragma unroll
+            for (int k = 0; k < NE; ++k) {
+                const bool ok = i0 + k < n_per_ch;
+                m4[k] = ok ? mu[(i0 + k) * C + c] : 0.0f;
+                s4[k] = ok ? sg[(i0 + k) * C + c] : 1.0f;
+            }
+        } else if (full) {
+            const float2 mv = *reinterpret_cast<const float2 *>(mu + base + i0);
+            const float2 sv = *reinterpret_cast<const float2 *>(sg + base + i0);
+            m4[0] = mv.x; m4[1] = mv.y;
+            s4[0] = sv.x; s4[1] = sv.y;
+        } else {
+#pragma unroll
+            for (int k = 0; k < NE; ++k) {
+                const bool ok = i0 + k < n_per_ch;
+                m4[k] = ok ? mu[base + i0 + k] : 0.0f;
+                s4[k] = ok ? sg[base + i0 + k] : 1.0f;
+            }
+        }
+        // ---- phase A: distortion of the NEARER neighbour on every level (du is monotone in |P - z|: one cost per level)
+        float du[NE][N1];
+        {
+            uint32_t g[NE];
+            double rinv[NE];
+#pragma unroll
+            for (int k = 0; k < NE; ++k) { g[k] = 0; rinv[k] = __ddiv_rn(1.0, (double)s4[k]); }
+#pragma unroll
+            for (int n = 0; n <= N; ++n) {
+                const int off4 = 4 * ((1 << n) - 1);
+                const int top4 = off4;
+#pragma unroll
+                for (int k = 0; k < NE; ++k) {
+                    const float pj = *reinterpret_cast<const float *>(tbb + off4 + g[k]);
+                    const bool below = pj < m4[k];
+                    float dmin;
+                    if (n == 0) {
+                        dmin = __fsub_rn(pj, m4[k]);
+                    } else {
+                        const uint32_t G4 = g[k] + (below ? 4u : 0u);
+                        int lo = (int)G4 - 4;
+                        lo = lo < 0 ? 0 : lo;
+                        if (n == N) lo = lo > top4 - 4 ? top4 - 4 : lo;
+                        const uint32_t hi4 = G4 > (uint32_t)top4 ? (uint32_t)top4 : G4;
+                        const float dl = __fsub_rn(*reinterpret_cast<const float *>(tbb + off4 + lo), m4[k]);
+                        const float dr = __fsub_rn(*reinterpret_cast<const float *>(tbb + off4 + hi4), m4[k]);
+                        dmin = fminf(fabsf(dl), fabsf(dr));
+                    }
+                    const float t = (float)__dmul_rn((double)dmin, rinv[k]);
+                    du[k][n] = __fmul_rn(0.5f, __fmul_rn(t, t));
+                    g[k] = 2 * g[k] + (below ? 4u : 0u);
+                }
+            }
+        }
+        // ---- thresholds, positions in the sorted sweep, guard bands, counters
+        uint32_t flags[NE];
+        uint32_t apos[NE][N];                                  // a_n, kept for the (rare) corrections
+#pragma unroll
+        for (int k = 0; k < NE; ++k) {
+            const bool valid = i0 + k < n_per_ch;
+            my_valid += valid ? 1u : 0u;
+            float Pm[N1];                                      // Pm[j] = min_{i <= n} (du_i - du_j) / (j - i)
+            float Tn[N];
+            uint64_t near[N];                                  // lanes whose threshold n has a sweep point inside its band
+            float big = du[k][0];
+#pragma unroll
+            for (int j = 1; j < N1; ++j) big = fmaxf(big, du[k][j]);
+            uint32_t fl = (!(big < kHullBig) || force_slow) ? 0xffffffffu : 0u;     // non-finite costs: every lambda re-solved
+            uint64_t any_near = 0;
+#pragma unroll
+            for (int n = 0; n < N; ++n) {
+#pragma unroll
+                for (int j = n + 1; j < N1; ++j) {
+                    const float r = __fmul_rn(__fsub_rn(du[k][n], du[k][j]), 1.0f / (float)(j - n));
+                    Pm[j] = n == 0 ? r : fminf(Pm[j], r);
+                }
+                float t = Pm[n + 1];
+#pragma unroll
+                for (int j = n + 2; j < N1; ++j) t = fmaxf(t, Pm[j]);
+                t = fminf(t, 1.0e38f);                         // inf / NaN (non-finite costs, flagged above) stay inside the tables
+                Tn[n] = t;
+                // position: bucket of the threshold's bit pattern, then the one sweep point that may share the bucket
+                int key = (int)(__float_as_uint(t) >> 16) - sw.key0;
+                key = (int)__float_as_uint(t) <= 0 ? 0 : key;                 // T <= 0: below every sweep point
+                key = key < 0 ? 0 : (key > sw.nkeys - 1 ? sw.nkeys - 1 : key);
+                const uint32_t cnt = lut[key];
+                const float s_m1 = sorted[cnt], s_0 = sorted[cnt + 1], s_p1 = sorted[cnt + 2];
+                const bool up = s_0 < t;
+                const uint32_t a = cnt + (up ? 1u : 0u);
+                const float lo = up ? s_0 : s_m1, hi = up ? s_p1 : s_0;       // lam_(a-1) < T <= lam_(a)
+                apos[k][n] = a;
+                // band |lambda - T| <= 2^-20 (du_n + |T| (n + 1)): every sweep point outside it is decided by the lines
+                const float G = __fmul_rn(fmaf(fabsf(t), (float)(n + 1), du[k][n]), 9.5367431640625e-07f);
+                const float dist = fminf(__fsub_rn(hi, t), __fsub_rn(t, lo));
+                near[n] = __builtin_amdgcn_ballot_w64(dist <= G);
+                any_near |= near[n];
+                if (valid) atomicAdd(&H[((uint32_t)n * LB + a) * 16u + copy], inc);
+            }
+            if (any_near != 0) {                               // rare: list the sweep points inside the band(s)
+#pragma unroll
+                for (int n = 0; n < N; ++n) {
+                    if (near[n] == 0) continue;
+                    if ((near[n] >> lane) & 1ull) {
+                        const float G = __fmul_rn(fmaf(fabsf(Tn[n]), (float)(n + 1), du[k][n]), 9.5367431640625e-07f);
+                        for (int l = 0; l < L; ++l)
+                            fl |= (fabsf(__fsub_rn(sw.lam[l], Tn[n])) <= G) ? (1u << l) : 0u;
+                    }
+                }
+            }
+            fl &= L >= 32 ? 0xffffffffu : ((1u << L) - 1u);
+            flags[k] = (valid && !never_flag) ? fl : 0u;
+        }
+        // ---- sweep points inside a guard band: literal scan for that (element, lambda), histogram corrected
+#pragma unroll
+        for (int k = 0; k < NE; ++k) {
+            while (__builtin_amdgcn_ballot_w64(flags[k] != 0u) != 0ull) {
+                if (flags[k] != 0u) {
+                    const int l = __builtin_ctz(flags[k]);
+                    flags[k] &= flags[k] - 1u;
+                    const int lo_ = sw.perm[l];
+                    const uint32_t rk = exact_rank_scan<N>(tb, m4[k], s4[k], penl + lo_ * PS);
+                    const int n_ex = N - __builtin_ctz(rk + 1u);
+                    int n_pred = 0;
+#pragma unroll
+                    for (int n = 0; n < N; ++n) n_pred += apos[k][n] > (uint32_t)l ? 1 : 0;
+                    if (n_ex != n_pred) {
+                        atomicAdd(&corr[l * N1 + n_ex], 1);
+                        atomicSub(&corr[l * N1 + n_pred], 1);
+                    }
+                }
+            }
+        }
+    }
+    atomicAdd(&n_valid, my_valid);
+    __syncthreads();
+    // counts[l][n] = #{a_{n-1} > l} - #{a_n > l} + corrections, with #{a_{-1} > l} = all elements and #{a_N > l} = 0
+    unsigned int *hs = reinterpret_cast<unsigned int *>(penl);          // [N][LB] sums over the 32 partial counters (penl is done)
+    static_assert(N * LB <= kMaxLambdaChunk * PS, "hs must fit the penalty staging area");
+    for (int i = threadIdx.x; i < N * LB; i += blockDim.x) {
+        unsigned int v = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const unsigned int w = H[i * 16 + j];
+            v += (w & 0xffffu) + (w >> 16);
+        }
+        hs[i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < N) {                                              // suffix sums: hs[n][a] := #{a_n >= a}
+        unsigned int run = 0;
+        for (int a = LB - 1; a >= 0; --a) { run += hs[threadIdx.x * LB + a]; hs[threadIdx.x * LB + a] = run; }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < L * N1; i += blockDim.x) {
+        const int l = i / N1, n = i - l * N1;
+        const long hi_cnt = n == 0 ? (long)n_valid : (long)hs[(n - 1) * LB + l + 1];
+        const long lo_cnt = n == N ? 0 : (long)hs[n * LB + l + 1];
+        const long v = hi_cnt - lo_cnt + corr[i];
+        if (v) atomicAdd(&level_counts[((long)sw.perm[l] * C + c) * N1 + n], (unsigned long long)v);
+    }
+}
+
 }  // namespace
 
 template <int N>
@@ -454,6 +699,59 @@ int launch_quant_fast(const float *mu, const float *sg, int64_t n_per_ch, int64_
         hipLaunchKernelGGL((k_quant_fast<N, 0>), grid, block, 0, st, mu, sg, (long)n_per_ch, (long)ch_stride, (int)n_ch, table,
                            pen, len, (int)L, out_idx, out_zhat, out_bits, (long)E, vec_ok, dbg, odd_pen, level_counts);
     VBQ_CHECK_LAUNCH("quant_fast");
+    return VBQ_OK;
+}
+
+// Host side of K1t: sort the sweep, check that the bucket table applies (distinct f32 values at least one bucket
+// apart, within 16 octaves), launch.  Returns 1 when the sweep is not eligible (the caller then takes the dense
+// counting kernel), VBQ_OK / an error otherwise.
+int launch_level_counts_hull10(const float *mu, const float *sg, int64_t n_per_ch, int64_t ch_stride, int32_t n_ch,
+                               const float *table, const float *pen, const double *lam, int32_t L, int vec_ok,
+                               unsigned long long *level_counts, hipStream_t st) {
+    static const bool off = [] { const char *e = getenv("VBQ_NO_HULL"); return e && e[0] == '1'; }();
+    if (off || L < 1 || L > 32) return 1;
+    HullSweep sw;
+    int order[32];
+    for (int i = 0; i < L; ++i) order[i] = i;
+    for (int i = 1; i < L; ++i)                              // insertion sort by the f32 value
+        for (int j = i; j > 0 && (float)lam[order[j]] < (float)lam[order[j - 1]]; --j) { const int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t; }
+    int prev_key = -1;
+    for (int i = 0; i < 32; ++i) { sw.lam[i] = kHullBig; sw.perm[i] = 0; }
+    for (int i = 0; i < L; ++i) {
+        const float v = (float)lam[order[i]];
+        if (!(v >= 1.9e-12f && v <= 1.8e19f)) return 1;
+        uint32_t bits;
+        memcpy(&bits, &v, 4);
+        const int key = (int)(bits >> 16);
+        if (key <= prev_key) return 1;                        // two sweep points in one bucket (or equal): dense kernel
+        prev_key = key;
+        sw.lam[i] = v;
+        sw.perm[i] = (unsigned char)order[i];
+    }
+    uint32_t b0;
+    memcpy(&b0, &sw.lam[0], 4);
+    sw.key0 = (int)(b0 >> 16);
+    sw.nkeys = prev_key - sw.key0 + 2;
+    sw.L = L;
+    if (sw.nkeys > kHullKeys) return 1;
+    const int64_t nquads = (n_per_ch + 1) / 2;
+    int64_t gx = (nquads + kFastThreads - 1) / kFastThreads;
+    int64_t cap = (int64_t)256 * 4 * 2 / n_ch;               // 4 workgroups per CU resident (35 KB of LDS each), two rounds
+    if (cap < 1) cap = 1;
+    if (gx > cap) {
+        const int64_t iters = gx;
+        int64_t best = cap, best_pad = ((iters + cap - 1) / cap) * cap - iters;
+        for (int64_t g = cap - 1; g >= (cap + 1) / 2 && best_pad > 0; --g) {
+            const int64_t pad = ((iters + g - 1) / g) * g - iters;
+            if (pad * best < best_pad * g) { best = g; best_pad = pad; }
+        }
+        gx = best;
+        if ((iters + gx - 1) / gx > 4000) gx = (iters + 3999) / 4000;     // 16-bit partial counters
+    }
+    static const int dbg = [] { const char *e = getenv("VBQ_FAST_DEBUG"); return e ? atoi(e) : 0; }();
+    hipLaunchKernelGGL((k_level_counts_hull<10>), dim3((unsigned)gx, (unsigned)n_ch), dim3(kFastThreads), 0, st, mu, sg,
+                       (long)n_per_ch, (long)ch_stride, (int)n_ch, table, pen, sw, vec_ok, level_counts, dbg);
+    VBQ_CHECK_LAUNCH("level_counts_hull");
     return VBQ_OK;
 }
 
