@@ -171,6 +171,21 @@ int vbq_argmax_candidates_f32(const float *d_P, const float *d_len, int32_t len_
                               int32_t *d_out_j, float *d_out_zhat, float *d_out_bits, void *stream);
 
 /* ----------------------------------------------------------------------------------
+ * The reference's first, xi-space encoder (img-compression/utils.py:215-304), float64 as there.
+ *   vbq_xi_intervals_f64  utils.get_all_N_bit_intervals (:215-260): d_left / d_right [N+1][K] = the two n-bit grid
+ *                         points around xi[k] for every bit budget n (n = 0: both 0.5; outside the grid: both the rim).
+ *   vbq_xi_select_f64     utils.encode_vectorized after its three callables (:291-303).  d_F, d_endpoints,
+ *                         d_unsquashed are [2][N+1][K] (left first, np.stack order): picks the better endpoint per budget
+ *                         (first maximum), subtracts lamb * n, picks the best budget (first maximum) and gathers
+ *                         z_hat, xi_hat, num_bits (int64, as NumPy's argmax) and the per-coordinate objective f_z_hat
+ *                         (the caller sums it: result['score'] = np.sum(f_z_hat)).
+ * squash / unsquash / fun are the caller's functions and stay where the caller evaluates them.
+ * ---------------------------------------------------------------------------------- */
+int vbq_xi_intervals_f64(const double *d_xi, int64_t K, int32_t N, double *d_left, double *d_right, void *stream);
+int vbq_xi_select_f64(const double *d_F, const double *d_endpoints, const double *d_unsquashed, int64_t K, int32_t N,
+                      double lamb, double *d_z_hat, int64_t *d_num_bits, double *d_xi_hat, double *d_f_z_hat, void *stream);
+
+/* ----------------------------------------------------------------------------------
  * K1n  Notebook solve.  Replaces compress_coordinates(means, stds, beta, bitlengths)
  *      (word-embeddings/compress-trained-word-embeddings.ipynb:429-443): f64 squared
  *      error against an f64 code book, penalty (2*beta)*sigma^2 rounded to f32 and

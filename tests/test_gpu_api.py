@@ -466,3 +466,33 @@ def test_numpy_order_moment(n):
     assert got == CO.numpy_sum_sq_f32(x)
     if n:
         assert got == np.sum(x ** 2)
+
+
+def test_xi_space_encoder_golden_g3_g4(golden):
+    """The reference's first encoder (utils.py:215-304) through vbq_amd.utils: the interval search (g3: the numba kernel's
+    outputs) and the whole encode_vectorized (g4: z_hat, num_bits, xi_hat, score for 5 lambdas with scipy's norm.cdf /
+    norm.ppf / norm.logpdf as the caller's functions), bit for bit, plus the rims and exact grid points."""
+    from scipy.stats import norm
+    from vbq_amd import utils
+    g3 = golden("g3_xi_intervals.npz")
+    n = int(g3["N"])
+    left = np.empty((n + 1, g3["x"].size))
+    right = np.empty_like(left)
+    utils.get_all_N_bit_intervals(g3["x"], n, left, right)
+    assert np.array_equal(left, g3["left"]) and np.array_equal(right, g3["right"])
+    x = np.array([0.0, 1.0, 0.5, 0.25, 0.75, 2.0 ** -11, 1 - 2.0 ** -11, 0.4375, 1 / 3, np.nextafter(0.5, 1), np.nextafter(0.5, 0)])
+    l2, r2 = np.empty((17, x.size)), np.empty((17, x.size))
+    utils.get_all_N_bit_intervals(x, 16, l2, r2)
+    lo, ro = O.xi_intervals(x, 16)
+    assert np.array_equal(l2, lo) and np.array_equal(r2, ro)
+    assert (l2[2, 7], r2[2, 7]) == (0.375, 0.625)                      # the reference docstring's known answer (utils.py:31-32)
+    g4 = golden("g4_encode_vectorized.npz")
+    mu, sigma = g4["mu"], g4["sigma"]
+    fun = lambda z: norm.logpdf(z, loc=mu, scale=sigma)                # what curry_normal_logpdf(backend=np) returns (utils.py:314-316)
+    for i, lamb in enumerate(g4["lambs"]):
+        r = utils.encode_vectorized(fun, mu, float(lamb), norm.cdf, norm.ppf, max_bits_per_coord=int(g4["N"]))
+        assert np.array_equal(r["z_hat"], g4["z_hat"][i]) and np.array_equal(r["xi_hat"], g4["xi_hat"][i])
+        assert np.array_equal(r["num_bits"], g4["num_bits"][i]) and r["num_bits"].dtype == np.int64
+        assert r["score"] == g4["score"][i]
+        ref = O.encode_vectorized(fun, mu, float(lamb), norm.cdf, norm.ppf, int(g4["N"]))
+        assert all(np.array_equal(r[k], ref[k]) for k in ("z_hat", "xi_hat", "num_bits")) and r["score"] == ref["score"]

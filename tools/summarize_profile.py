@@ -19,13 +19,16 @@ src = os.path.join(root, "gpurun_out")
 dst = os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
 
-KERNELS = ("k_quant_fast", "k_hist_flat", "k_transpose", "k_prepare_penalties", "k_quant_tiled", "k_quant_flat",
-           "k_gather", "k_hist_tiled", "k_quant_notebook")
+KERNELS = ("k_level_counts_hull", "k_quant_fast", "k_hist_flat", "k_transpose", "k_prepare_penalties", "k_quant_tiled",
+           "k_quant_flat", "k_gather", "k_hist_tiled", "k_quant_notebook", "k_lut_lengths")
 
 
 def short(name):
+    """Kernel family; the counting instantiation of the fast kernel (template mode 2) is reported on its own."""
     for k in KERNELS:
         if k in name:
+            if k == "k_quant_fast" and ("ELi2EE" in name or ", 2>" in name):
+                return "k_quant_fast_count"
             return k
     return None
 
@@ -94,6 +97,11 @@ for k, m in merged.items():
             c["clock_GHz"] = cyc / c["dur_us_sq1"] / 1e3
             simd_quads = cyc * 1024 / 4.0                                # 256 CUs x 4 SIMDs, quad-cycles
             c["valu_active_over_simd_time"] = c.get("SQ_ACTIVE_INST_VALU", 0) / simd_quads
+            # share of the SIMDs' issue time spent issuing VALU work: SQ_ACTIVE_INST_VALU counts a quad-cycle per VALU
+            # instruction issued, the 2-cycle ops (add / sub / mul / logic) included, so it over-counts those by 2x;
+            # with the measured split of the K1 lambda loop (profiles/*_isa.txt: ~55 % two-cycle, 45 % four-cycle
+            # instructions) the issue cycles are ~0.72 quad-cycles per instruction
+            c["valu_issue_frac"] = min(1.0, 0.72 * c.get("SQ_ACTIVE_INST_VALU", 0) / simd_quads)
             c["waves_per_simd"] = c.get("SQ_WAVE_CYCLES", 0) / simd_quads
             for n in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
                 if n in c and c.get("SQ_WAVE_CYCLES"):

@@ -38,6 +38,9 @@ SIGNATURES = {
                                                C.c_void_p, C.c_void_p, C.c_void_p]),
     "vbq_histogram_rows_u16": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                          C.c_int32, C.c_int64, C.c_int64, C.c_void_p]),
+    "vbq_xi_intervals_f64": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vbq_xi_select_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_double, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vbq_quantize_notebook_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_double),
                                             C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vbq_histogram_u16": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,

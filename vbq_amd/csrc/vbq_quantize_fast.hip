@@ -438,16 +438,43 @@ k_quant_fast(const float *__restrict__ mu, const float *__restrict__ sg, long n_
 // that element with the literal 21-candidate scan and the histogram corrected by (+1 exact level, -1 predicted level).
 // About 3 in 10 000 (element, threshold) pairs take that path.  tests/test_gpu_twopass.py forces it (exact ties, equal
 // costs, thresholds on sweep points) and tools/stress_parity.py --levels compares 1e9+ solves with the C oracle.
+#ifndef VBQ_HULL_WAVES
+#define VBQ_HULL_WAVES 4
+#endif
+constexpr int kHullKeys = 2048;         // 16 octaves of 128 buckets
+// v_min_f32 / v_max_f32 as they are (IEEE mode: a NaN operand loses).  fminf / fmaxf make the compiler canonicalise
+// operands it cannot prove quiet (a v_max x, x in front of every second min of the threshold recurrences).
+__device__ __forceinline__ float vmin(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float vmax(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float vmin3abs(float a, float b, float c) {       // min(|a|, |b|, |c|)
+    float r;
+    asm("v_min3_f32 %0, |%1|, |%2|, |%3|" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 struct HullSweep {
     float lam[32];          // the sweep rounded to f32, ascending
     unsigned char perm[32]; // position of lam[l] in the caller's order
     int L, key0, nkeys;     // keys = float bits >> 16 (sign, exponent, 7 mantissa bits); bucket b <-> key0 + b
+    unsigned char lut[kHullKeys];   // lut[b] = #{ l : lam[l] below the lower edge of bucket b }
 };
-constexpr int kHullKeys = 2048;         // 16 octaves of 128 buckets
 constexpr float kHullBig = 3.0e38f;
 
 template <int N>
-__global__ void __launch_bounds__(kFastThreads, 4)
+__global__ void __launch_bounds__(kFastThreads, VBQ_HULL_WAVES)
 k_level_counts_hull(const float *__restrict__ mu, const float *__restrict__ sg, long n_per_ch, long ch_stride, int C,
                     const float *__restrict__ table, const float *__restrict__ pen, HullSweep sw, int vec_ok,
                     unsigned long long *__restrict__ level_counts, int dbg) {
@@ -458,8 +485,8 @@ k_level_counts_hull(const float *__restrict__ mu, const float *__restrict__ sg, 
     constexpr int LB = 33;                                    // positions 0..32
     __shared__ float tb[T + 1];
     __shared__ __align__(16) float penl[kMaxLambdaChunk * PS];
-    __shared__ unsigned char lut[kHullKeys];
-    __shared__ float sorted[36];                              // [0] = -big, [1 + l] = lam[l], then +big
+    __shared__ __align__(4) unsigned char lut[kHullKeys];
+    __shared__ float4 rec[34];                                // rec[i] = { lam[i-1], lam[i], lam[i+1], - } with -big / +big outside
     __shared__ unsigned int H[N * LB * 16];                   // [n][a][16 words x 2 halves]
     __shared__ int corr[kMaxLambdaChunk * N1];
     __shared__ unsigned int n_valid;
@@ -472,14 +499,12 @@ k_level_counts_hull(const float *__restrict__ mu, const float *__restrict__ sg, 
     }
     for (int i = threadIdx.x; i < N * LB * 16; i += blockDim.x) H[i] = 0;
     for (int i = threadIdx.x; i < L * N1; i += blockDim.x) corr[i] = 0;
-    for (int b = threadIdx.x; b < kHullKeys; b += blockDim.x) {     // lut[b] = #{ l : lam[l] < lower edge of bucket b }
-        int cnt = 0;
-        for (int l = 0; l < L; ++l) cnt += ((int)(__float_as_uint(sw.lam[l]) >> 16) < sw.key0 + b) ? 1 : 0;
-        lut[b] = (unsigned char)cnt;
-    }
-    if (threadIdx.x < 36) {
-        const int l = (int)threadIdx.x - 1;
-        sorted[threadIdx.x] = l < 0 ? -kHullBig : (l < L ? sw.lam[l] : kHullBig);
+    for (int b = threadIdx.x; b < kHullKeys / 4; b += blockDim.x)   // the bucket table travels in the kernel arguments
+        reinterpret_cast<uint32_t *>(lut)[b] = reinterpret_cast<const uint32_t *>(sw.lut)[b];
+    if (threadIdx.x < 34) {
+        const int i = (int)threadIdx.x;
+        auto at = [&](int l) { return l < 0 ? -kHullBig : (l < L ? sw.lam[l < 32 ? l : 31] : kHullBig); };
+        rec[i] = make_float4(at(i - 1), at(i), at(i + 1), 0.0f);
     }
     if (threadIdx.x == 0) n_valid = 0;
     __syncthreads();
@@ -536,14 +561,13 @@ k_level_counts_hull(const float *__restrict__ mu, const float *__restrict__ sg, 
                     if (n == 0) {
                         dmin = __fsub_rn(pj, m4[k]);
                     } else {
-                        const uint32_t G4 = g[k] + (below ? 4u : 0u);
-                        int lo = (int)G4 - 4;
-                        lo = lo < 0 ? 0 : lo;
-                        if (n == N) lo = lo > top4 - 4 ? top4 - 4 : lo;
-                        const uint32_t hi4 = G4 > (uint32_t)top4 ? (uint32_t)top4 : G4;
-                        const float dl = __fsub_rn(*reinterpret_cast<const float *>(tbb + off4 + lo), m4[k]);
-                        const float dr = __fsub_rn(*reinterpret_cast<const float *>(tbb + off4 + hi4), m4[k]);
-                        dmin = fminf(fabsf(dl), fabsf(dr));
+                        // the visited point is one neighbour of z on this level; the other one sits on z's side of it
+                        // (the same point again at the rim: the deepest level's one-slot-back quirk, quantizer.py:54-57,
+                        // only ever moves the FARTHER candidate, which a minimum does not see)
+                        int o4 = (int)g[k] + (below ? 4 : -4);
+                        o4 = o4 < 0 ? 0 : (o4 > top4 ? top4 : o4);
+                        const float po = *reinterpret_cast<const float *>(tbb + off4 + o4);
+                        dmin = fminf(fabsf(__fsub_rn(pj, m4[k])), fabsf(__fsub_rn(po, m4[k])));
                     }
                     const float t = (float)__dmul_rn((double)dmin, rinv[k]);
                     du[k][n] = __fmul_rn(0.5f, __fmul_rn(t, t));
@@ -558,12 +582,14 @@ k_level_counts_hull(const float *__restrict__ mu, const float *__restrict__ sg, 
         for (int k = 0; k < NE; ++k) {
             const bool valid = i0 + k < n_per_ch;
             my_valid += valid ? 1u : 0u;
+            const unsigned int vinc = valid ? inc : 0u;
             float Pm[N1];                                      // Pm[j] = min_{i <= n} (du_i - du_j) / (j - i)
             float Tn[N];
             uint64_t near[N];                                  // lanes whose threshold n has a sweep point inside its band
             float big = du[k][0];
 #pragma unroll
-            for (int j = 1; j < N1; ++j) big = fmaxf(big, du[k][j]);
+            for (int j = 1; j + 1 < N1; j += 2) big = vmax3(big, du[k][j], du[k][j + 1]);
+            if ((N1 & 1) == 0) big = vmax(big, du[k][N1 - 1]);
             uint32_t fl = (!(big < kHullBig) || force_slow) ? 0xffffffffu : 0u;     // non-finite costs: every lambda re-solved
             uint64_t any_near = 0;
 #pragma unroll
@@ -571,29 +597,32 @@ k_level_counts_hull(const float *__restrict__ mu, const float *__restrict__ sg, 
 #pragma unroll
                 for (int j = n + 1; j < N1; ++j) {
                     const float r = __fmul_rn(__fsub_rn(du[k][n], du[k][j]), 1.0f / (float)(j - n));
-                    Pm[j] = n == 0 ? r : fminf(Pm[j], r);
+                    Pm[j] = n == 0 ? r : vmin(Pm[j], r);
                 }
                 float t = Pm[n + 1];
+                {
+                    int j = n + 2;
 #pragma unroll
-                for (int j = n + 2; j < N1; ++j) t = fmaxf(t, Pm[j]);
-                t = fminf(t, 1.0e38f);                         // inf / NaN (non-finite costs, flagged above) stay inside the tables
+                    for (; j + 1 < N1; j += 2) t = vmax3(t, Pm[j], Pm[j + 1]);
+                    if (j < N1) t = vmax(t, Pm[j]);
+                }
+                t = vmin(t, 1.0e38f);                         // inf / NaN (non-finite costs, flagged above) stay inside the tables
                 Tn[n] = t;
-                // position: bucket of the threshold's bit pattern, then the one sweep point that may share the bucket
-                int key = (int)(__float_as_uint(t) >> 16) - sw.key0;
-                key = (int)__float_as_uint(t) <= 0 ? 0 : key;                 // T <= 0: below every sweep point
-                key = key < 0 ? 0 : (key > sw.nkeys - 1 ? sw.nkeys - 1 : key);
+                // position: bucket of the threshold's bit pattern (an arithmetic shift keeps T <= 0 negative, so one
+                // median clamps "below the sweep", "above it" and the table range), then the one sweep point that may
+                // share the bucket
+                const int key = min(max(((int)__float_as_uint(t) >> 16) - sw.key0, 0), sw.nkeys - 1);    // v_med3_i32
                 const uint32_t cnt = lut[key];
-                const float s_m1 = sorted[cnt], s_0 = sorted[cnt + 1], s_p1 = sorted[cnt + 2];
-                const bool up = s_0 < t;
-                const uint32_t a = cnt + (up ? 1u : 0u);
-                const float lo = up ? s_0 : s_m1, hi = up ? s_p1 : s_0;       // lam_(a-1) < T <= lam_(a)
+                const float4 nb = rec[cnt];                    // { lam_(cnt-1), lam_(cnt), lam_(cnt+1) }: one 16-byte read
+                const uint32_t a = cnt + (nb.y < t ? 1u : 0u); // lam_(a-1) < T <= lam_(a)
                 apos[k][n] = a;
-                // band |lambda - T| <= 2^-20 (du_n + |T| (n + 1)): every sweep point outside it is decided by the lines
+                // band |lambda - T| <= 2^-20 (du_n + |T| (n + 1)): every sweep point outside it is decided by the lines.
+                // T lies between lam_(cnt-1) and lam_(cnt+1), so its distance to the sweep is the smallest of the three.
                 const float G = __fmul_rn(fmaf(fabsf(t), (float)(n + 1), du[k][n]), 9.5367431640625e-07f);
-                const float dist = fminf(__fsub_rn(hi, t), __fsub_rn(t, lo));
+                const float dist = vmin3abs(__fsub_rn(t, nb.x), __fsub_rn(t, nb.y), __fsub_rn(t, nb.z));
                 near[n] = __builtin_amdgcn_ballot_w64(dist <= G);
                 any_near |= near[n];
-                if (valid) atomicAdd(&H[((uint32_t)n * LB + a) * 16u + copy], inc);
+                atomicAdd(&H[((uint32_t)n * LB + a) * 16u + copy], vinc);      // padding lanes add 0: no exec juggling
             }
             if (any_near != 0) {                               // rare: list the sweep points inside the band(s)
 #pragma unroll
@@ -619,7 +648,7 @@ k_level_counts_hull(const float *__restrict__ mu, const float *__restrict__ sg, 
                     const int lo_ = sw.perm[l];
                     const uint32_t rk = exact_rank_scan<N>(tb, m4[k], s4[k], penl + lo_ * PS);
                     const int n_ex = N - __builtin_ctz(rk + 1u);
-                    int n_pred = 0;
+                    int n_pred = 0;                            // the level the counters assumed: #{ n : a_n > l }
 #pragma unroll
                     for (int n = 0; n < N; ++n) n_pred += apos[k][n] > (uint32_t)l ? 1 : 0;
                     if (n_ex != n_pred) {
@@ -734,9 +763,21 @@ int launch_level_counts_hull10(const float *mu, const float *sg, int64_t n_per_c
     sw.nkeys = prev_key - sw.key0 + 2;
     sw.L = L;
     if (sw.nkeys > kHullKeys) return 1;
+    {
+        int l = 0;
+        for (int b = 0; b < kHullKeys; ++b) {
+            while (l < L) {
+                uint32_t bits;
+                memcpy(&bits, &sw.lam[l], 4);
+                if ((int)(bits >> 16) < sw.key0 + b) ++l; else break;
+            }
+            sw.lut[b] = (unsigned char)l;
+        }
+    }
     const int64_t nquads = (n_per_ch + 1) / 2;
     int64_t gx = (nquads + kFastThreads - 1) / kFastThreads;
-    int64_t cap = (int64_t)256 * 4 * 2 / n_ch;               // 4 workgroups per CU resident (35 KB of LDS each), two rounds
+    static const int rounds = [] { const char *e = getenv("VBQ_HULL_ROUNDS"); return e ? atoi(e) : 1; }();
+    int64_t cap = (int64_t)256 * 4 * rounds / n_ch;          // 4 workgroups per CU resident (35 KB of LDS each)
     if (cap < 1) cap = 1;
     if (gx > cap) {
         const int64_t iters = gx;

@@ -96,6 +96,48 @@ def quantize_indep_dims(z, code_points, code_lengths, fun, lamb, backend=np, mod
     return Zd[lamb][0], Bd[lamb][0]
 
 
+def get_all_N_bit_intervals(x, N, left_endpoints, right_endpoints):
+    """utils.py:215-260 (the numba kernel), same in-place signature: fills the two (N+1) x K float64 arrays with the
+    n-bit grid points around every x[k].  Runs on the GPU (vbq_xi_intervals_f64)."""
+    from . import _lib, ops
+    dev = _device()
+    xd = torch.from_numpy(np.ascontiguousarray(np.asarray(x, dtype=np.float64))).to(dev)
+    K = xd.numel()
+    ld = torch.empty((N + 1, K), dtype=torch.float64, device=dev)
+    rd = torch.empty((N + 1, K), dtype=torch.float64, device=dev)
+    _lib.check(_lib.lib().vbq_xi_intervals_f64(ops._ptr(xd), K, int(N), ops._ptr(ld), ops._ptr(rd), ops._stream(xd)),
+               "vbq_xi_intervals_f64")
+    left_endpoints[...] = ld.cpu().numpy()
+    right_endpoints[...] = rd.cpu().numpy()
+
+
+def encode_vectorized(fun, z, lamb, squash, unsquash, max_bits_per_coord=16):
+    """utils.py:263-304, the xi-space encoder.  `fun`, `squash`, `unsquash` are the caller's NumPy functions and are
+    evaluated where the caller defined them; the interval search before them and the selection after them run on the GPU
+    in the reference's float64.  Returns the reference's dict (z_hat, score, num_bits, xi_hat)."""
+    from . import _lib, ops
+    dev = _device()
+    z = np.asarray(z)
+    K, N = len(z), int(max_bits_per_coord)
+    xi = np.asarray(squash(z), dtype=np.float64)
+    xd = torch.from_numpy(np.ascontiguousarray(xi)).to(dev)
+    ends = torch.empty((2, N + 1, K), dtype=torch.float64, device=dev)          # np.stack([left, right]) (:286)
+    h = _lib.lib()
+    _lib.check(h.vbq_xi_intervals_f64(ops._ptr(xd), K, N, ops._ptr(ends[0]), ops._ptr(ends[1]), ops._stream(xd)),
+               "vbq_xi_intervals_f64")
+    endpoints = ends.cpu().numpy()
+    unsquashed = np.ascontiguousarray(np.asarray(unsquash(endpoints), dtype=np.float64))      # 2 x (N+1) x K (:287)
+    F = np.ascontiguousarray(np.asarray(fun(unsquashed), dtype=np.float64))                    # (:288)
+    Fd, ud = torch.from_numpy(F).to(dev), torch.from_numpy(unsquashed).to(dev)
+    z_hat = torch.empty(K, dtype=torch.float64, device=dev)
+    xi_hat = torch.empty(K, dtype=torch.float64, device=dev)
+    f_z = torch.empty(K, dtype=torch.float64, device=dev)
+    nb = torch.empty(K, dtype=torch.int64, device=dev)
+    _lib.check(h.vbq_xi_select_f64(ops._ptr(Fd), ops._ptr(ends), ops._ptr(ud), K, N, float(lamb), ops._ptr(z_hat), ops._ptr(nb),
+                                   ops._ptr(xi_hat), ops._ptr(f_z), ops._stream(Fd)), "vbq_xi_select_f64")
+    return dict(z_hat=z_hat.cpu().numpy(), score=np.sum(f_z.cpu().numpy()), num_bits=nb.cpu().numpy(), xi_hat=xi_hat.cpu().numpy())
+
+
 def convert_to_db(d):
     """utils.py:497-499 (BMSHJ ICLR 2018, p. 8)."""
     return -10 * np.log10(1 - d)
