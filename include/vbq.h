@@ -109,6 +109,11 @@ int vbq_device_name(int dev, char *buf, size_t buflen);
  * ---------------------------------------------------------------------------------- */
 size_t vbq_quantize_workspace_bytes(int32_t n_ch, int32_t n_lambda, int32_t N);
 
+/* The solve's precondition, checkable: d_bad[0] += #{mu not finite}, d_bad[1] += #{sigma not finite or <= 0} (u32[2],
+ * device, zero it first).  The reference lets such values flow through tf.argmax (NaN scores, whatever index results);
+ * here they are outside the contract of vbq_quantize_f32, and this is how a caller finds out beforehand. */
+int vbq_check_inputs_f32(const float *d_mu, const float *d_sigma, int64_t n, uint32_t *d_bad, void *stream);
+
 int vbq_quantize_f32(const float *d_mu, const float *d_sigma, int64_t n_rows, int32_t n_ch,
                      int32_t layout, const float *d_table_lm, const float *d_level_len,
                      const double *h_lambdas, int32_t n_lambda, int32_t N, int32_t mode,

@@ -332,6 +332,9 @@ def test_model_table_cache_follows_replaced_models(golden):
     q.entropy_models = {l: np.zeros((C, T), np.float32) for l in lambs}
     d = q.compress_latents(means, logvars, lambs)
     assert all(not d["num_bits"][l].any() for l in lambs)
+    # an edit IN PLACE cannot be seen by an identity-keyed cache: cached arrays are read-only, so it fails loudly
+    with pytest.raises(ValueError, match="read-only"):
+        q.entropy_models[lambs[0]][0, 0] = 5.0
 
 
 def test_entry_points_are_graph_capturable():
@@ -496,3 +499,27 @@ def test_xi_space_encoder_golden_g3_g4(golden):
         assert r["score"] == g4["score"][i]
         ref = O.encode_vectorized(fun, mu, float(lamb), norm.cdf, norm.ppf, int(g4["N"]))
         assert all(np.array_equal(r[k], ref[k]) for k in ("z_hat", "xi_hat", "num_bits")) and r["score"] == ref["score"]
+
+
+def test_input_validation_is_available_and_off_by_default():
+    from vbq_amd import ChannelwisePriorCDFQuantizer, ops, priors
+    mu = torch.randn(5000, device="cuda")
+    sg = torch.rand(5000, device="cuda") + 0.1
+    ops.check_inputs(mu, sg)
+    for bad_mu, bad_sg, what in ((float("nan"), 1.0, "1 non-finite means"), (float("inf"), 1.0, "1 non-finite means"),
+                                 (0.0, 0.0, "1 standard deviations"), (0.0, -1.0, "1 standard deviations"),
+                                 (0.0, float("nan"), "1 standard deviations")):
+        m, s = mu.clone(), sg.clone()
+        m[4321], s[4321] = bad_mu, bad_sg
+        with pytest.raises(ValueError, match=what):
+            ops.check_inputs(m, s)
+    q = ChannelwisePriorCDFQuantizer(2, N, validate_inputs=True)
+    q.build_code_points(priors.FactoredGaussianPrior(np.zeros(2), np.ones(2)))
+    means = np.zeros((10, 2), np.float32)
+    stds = np.ones((10, 2), np.float32)
+    q.compress_batch_channel_latents(means, stds, [1.0])
+    stds[3, 1] = 0.0
+    with pytest.raises(ValueError, match="standard deviations"):
+        q.compress_batch_channel_latents(means, stds, [1.0])
+    q.validate_inputs = False                                          # the reference's behaviour: no check, no exception
+    q.compress_batch_channel_latents(means, np.ones((10, 2), np.float32), [1.0])

@@ -25,6 +25,7 @@ SIGNATURES = {
     "vbq_device_count": (C.c_int, []),
     "vbq_device_name": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t]),
     "vbq_quantize_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
+    "vbq_check_inputs_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "vbq_quantize_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                    C.POINTER(C.c_double), C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

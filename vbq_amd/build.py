@@ -53,6 +53,8 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
     srcs = hip_sources()
     headers = [os.path.join(CSRC, "vbq_common.h"), os.path.join(INCLUDE, "vbq.h")]
     extra = os.environ.get("VBQ_EXTRA_HIPCC_FLAGS", "").split()       # developer experiments only
+    if os.environ.get("VBQ_ONLY_N10") == "1":   # the reference's bit depth alone (post_process.py:117): a third of the build time
+        extra.append("-DVBQ_ONLY_N10")
     objdir = os.path.join(LIBDIR, "obj")
     flags_tag = os.path.join(objdir, "flags.txt")
     tag = " ".join(HIPCC_FLAGS + extra)

@@ -596,6 +596,35 @@ k_index_max(const uint16_t *__restrict__ idx, long n, unsigned int *__restrict__
 }  // namespace
 }  // namespace vbq
 
+namespace vbq {
+namespace {
+__global__ void __launch_bounds__(256)
+k_check_inputs(const float *__restrict__ mu, const float *__restrict__ sg, long n, unsigned int *__restrict__ out) {
+    unsigned int bad_mu = 0, bad_sg = 0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float m = mu[i], s = sg[i];
+        bad_mu += !(fabsf(m) <= 3.4028234e38f) ? 1u : 0u;                       // NaN or infinity
+        bad_sg += !(s > 0.0f && s <= 3.4028234e38f) ? 1u : 0u;                  // NaN, infinity, zero or negative
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { bad_mu += __shfl_down(bad_mu, o, 64); bad_sg += __shfl_down(bad_sg, o, 64); }
+    if ((threadIdx.x & 63) == 0 && (bad_mu | bad_sg)) { atomicAdd(&out[0], bad_mu); atomicAdd(&out[1], bad_sg); }
+}
+}  // namespace
+}  // namespace vbq
+
+extern "C" int vbq_check_inputs_f32(const float *d_mu, const float *d_sigma, int64_t n, uint32_t *d_bad, void *stream) {
+    using namespace vbq;
+    VBQ_REQUIRE(n >= 0, VBQ_ERR_INVALID_ARGUMENT, "vbq_check_inputs_f32: n < 0");
+    if (n == 0) return VBQ_OK;
+    VBQ_REQUIRE(d_mu && d_sigma && d_bad, VBQ_ERR_INVALID_ARGUMENT, "vbq_check_inputs_f32: null pointer");
+    int64_t gx = (n + 255) / 256;
+    if (gx > 4096) gx = 4096;
+    hipLaunchKernelGGL(k_check_inputs, dim3((unsigned)gx), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), d_mu, d_sigma, (long)n, d_bad);
+    VBQ_CHECK_LAUNCH("check_inputs");
+    return VBQ_OK;
+}
+
 extern "C" int vbq_index_max_u16(const uint16_t *d_idx, int64_t n, uint32_t *d_max, void *stream) {
     using namespace vbq;
     VBQ_REQUIRE(n >= 0, VBQ_ERR_INVALID_ARGUMENT, "vbq_index_max_u16: n < 0");

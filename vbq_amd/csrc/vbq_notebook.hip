@@ -359,12 +359,14 @@ extern "C" int vbq_quantize_notebook_f64(const float *d_means, const float *d_st
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     switch (N) {
         case 10: return launch_notebook<10>(d_means, d_stds, n, d_codebook_lm, h_betas, n_beta, d_out_idx, d_out_val, st);
+#ifndef VBQ_ONLY_N10
         case 9: return launch_notebook<9>(d_means, d_stds, n, d_codebook_lm, h_betas, n_beta, d_out_idx, d_out_val, st);
         case 8: return launch_notebook<8>(d_means, d_stds, n, d_codebook_lm, h_betas, n_beta, d_out_idx, d_out_val, st);
         case 7: return launch_notebook<7>(d_means, d_stds, n, d_codebook_lm, h_betas, n_beta, d_out_idx, d_out_val, st);
         case 6: return launch_notebook<6>(d_means, d_stds, n, d_codebook_lm, h_betas, n_beta, d_out_idx, d_out_val, st);
         case 5: return launch_notebook<5>(d_means, d_stds, n, d_codebook_lm, h_betas, n_beta, d_out_idx, d_out_val, st);
         case 4: return launch_notebook<4>(d_means, d_stds, n, d_codebook_lm, h_betas, n_beta, d_out_idx, d_out_val, st);
+#endif
         default:
             set_error("vbq_quantize_notebook_f64: max_codepoint_length N=%d not built (have 4 ... 10)", N);
             return VBQ_ERR_UNSUPPORTED;

@@ -125,6 +125,20 @@ def quantize(mu: torch.Tensor, sigma: torch.Tensor, table_lm: torch.Tensor, lamb
     return out if len(out) > 1 else idx
 
 
+def check_inputs(mu: torch.Tensor, sigma: torch.Tensor):
+    """vbq_check_inputs_f32: raise ValueError when mu holds NaN / infinity or sigma holds NaN / infinity / values <= 0 --
+    the inputs vbq_quantize_f32 does not define an answer for (synchronises: one 8-byte read)."""
+    mu = _dev(mu, torch.float32, "mu")
+    sigma = _dev(sigma, torch.float32, "sigma")
+    if mu.shape != sigma.shape:
+        raise ValueError(f"mu {tuple(mu.shape)} and sigma {tuple(sigma.shape)} differ in shape")
+    bad = torch.zeros(2, dtype=torch.uint32, device=mu.device)
+    check(_lib.lib().vbq_check_inputs_f32(_ptr(mu), _ptr(sigma), mu.numel(), _ptr(bad), _stream(mu)), "vbq_check_inputs_f32")
+    b = bad.cpu().numpy()
+    if b[0] or b[1]:
+        raise ValueError(f"invalid latents: {int(b[0])} non-finite means, {int(b[1])} standard deviations that are not finite and positive")
+
+
 def level_counts(mu: torch.Tensor, sigma: torch.Tensor, table_lm: torch.Tensor, lambdas: Sequence[float], *,
                  N: int = 10, level_len: Optional[torch.Tensor] = None, layout="bc", out: Optional[torch.Tensor] = None,
                  workspace: Optional[torch.Tensor] = None):

@@ -47,7 +47,8 @@ def _default_device():
 
 
 class ChannelwisePriorCDFQuantizer:
-    def __init__(self, num_channels, max_bits_per_coord, float_type="float32", int_type="int32", device=None):
+    def __init__(self, num_channels, max_bits_per_coord, float_type="float32", int_type="int32", device=None,
+                 validate_inputs=False):
         if float_type != "float32":
             raise ValueError("only float_type='float32' is supported (the reference default, quantizer.py:14)")
         self.max_bits_per_coord = int(max_bits_per_coord)
@@ -59,6 +60,10 @@ class ChannelwisePriorCDFQuantizer:
         self.entropy_models = None
         self.process_group = None          # set to a torch.distributed group to all-reduce the histograms
         self._device = device
+        # True: every batch is checked on the device for NaN / infinite means and non-positive / non-finite standard
+        # deviations before it is solved (ValueError; costs one synchronisation per call).  The reference has no such
+        # check -- NaNs flow through tf.argmax there -- so it is off by default.
+        self.validate_inputs = bool(validate_inputs)
         self._dev_cache: Dict[str, torch.Tensor] = {}
 
     # ------------------------------------------------------------------ state / pickling
@@ -187,19 +192,29 @@ class ChannelwisePriorCDFQuantizer:
         sg = sg.to(self.device, torch.float32)
         if mu.dim() != 2 or mu.shape[1] != self.num_channels or mu.shape != sg.shape:
             raise ValueError(f"expected means/stds of shape [B, {self.num_channels}], got {tuple(mu.shape)} / {tuple(sg.shape)}")
+        if getattr(self, "validate_inputs", False):
+            ops.check_inputs(mu.contiguous(), sg.contiguous())
         # channel-major planes [C, B]
         return ops.transpose(mu.contiguous()), ops.transpose(sg.contiguous())
 
     def _keyed_dev(self, name: str, arrays, builder):
         """Device copy of a table assembled from per-lambda model arrays, rebuilt only when one of those arrays is
         replaced.  Keyed on the arrays' identities; the cache entry holds the arrays, so an id cannot be reused by a
-        new object while the entry lives.  (Editing a model array in place is not detected.)"""
+        new object while the entry lives.  An edit IN PLACE would leave the device copy stale without a trace, so the
+        cached arrays are made read-only: such an edit now raises (NumPy's "assignment destination is read-only");
+        replace the dict entry with a new array instead and the copy is rebuilt."""
         arrays = list(arrays)
         hit = self._dev_cache.get(name)
         if (hit is not None and len(hit[0]) == len(arrays) and all(a is b for a, b in zip(hit[0], arrays))
                 and hit[1].device == self.device):
             return hit[1]
         t = builder().to(self.device)
+        for a in arrays:
+            if isinstance(a, np.ndarray):
+                try:
+                    a.setflags(write=False)
+                except ValueError:
+                    pass
         self._dev_cache[name] = (arrays, t)
         return t
 
@@ -318,6 +333,9 @@ class ChannelwisePriorCDFQuantizer:
         if models_dev is not None:   # the device copies compress_latents will ask for are already here
             self._dev_cache["entropy_models"] = ([self.entropy_models[lamb] for lamb in lambs], models_dev)
         self._dev_cache["level_len"] = ([self.raw_code_length_entropy_models[lamb] for lamb in lambs], level_len)
+        for d in (self.entropy_models, self.raw_code_length_entropy_models):
+            for a in d.values():
+                a.setflags(write=False)          # see _keyed_dev: in-place edits must not go unnoticed
         return None
 
     @property
