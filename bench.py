@@ -4,8 +4,8 @@
     python bench.py --gpus N --steps K --warmup W
 
 One "step" = one whole entropy-model build of the reference (quantizer.py:82-150) over one batch, as
-vbq_amd.pipeline.EntropyModelBuild runs it: [layout change] -> pass 1 (K1h: 32-lambda solve with raw lengths +
-bit-length histogram) -> length table -> pass 2 (K1: 32-lambda solve with corrected lengths -> rank indices;
+vbq_amd.pipeline.EntropyModelBuild runs it: [layout change] -> pass 1 (K1t: 32-lambda solve with raw lengths +
+bit-length histogram, from 10 thresholds per element instead of a loop over lambda) -> length table -> pass 2 (K1: 32-lambda solve with corrected lengths -> rank indices;
 K2: their per-(lambda, channel) histogram) -> code-length models,
 and, with N > 1, the RCCL all-reduces of the two histograms.  Every (element, lambda) is therefore solved TWICE per
 step; `value` = solves ("quantized latents") per second over all ranks.  Inputs are resident in HBM before the
@@ -142,8 +142,10 @@ def committed_counters(workload, rows, C, L):
                 if "SQ_INSTS_VALU" in sqc:          # why the HBM fraction is what it is: the kernel is VALU-issue-bound
                     valu = {"valu_wave_instructions_per_pass": sqc["SQ_INSTS_VALU"] * k.get("launches_per_pass", 1),
                             "valu_instructions_per_latent": sqc["SQ_INSTS_VALU"] * k.get("launches_per_pass", 1) * 64.0 / (rows * C * L),
-                            "clock_GHz_under_load": sqc.get("clock_GHz"), "valu_issue_frac": k.get("valu_issue_frac"),
-                            "source": src}
+                            "clock_GHz_under_load": sqc.get("clock_GHz"),
+                            # share of the SIMDs' issue cycles spent on VALU instructions (quad-cycles per instruction
+                            # weighted by the loop's mix of 2- and 4-cycle ops): the kernel's real ceiling
+                            "valu_issue_frac": sqc.get("valu_issue_frac"), "source": src}
                 return k["hbm_bytes_per_launch"] * k.get("launches_per_pass", 1), src, valu
     except Exception:
         pass
@@ -280,9 +282,9 @@ def run_workload(name, args, torch, dist, dev, rank, world, steps, warmup, detai
                      "pass_ms": k1_ms, "latents_per_s_kernel_only": E * L / (k1_ms * 1e-3), "valu": valu,
                      "note": "K2 of the previous row chunk runs concurrently on a second stream" if k1_n > 1 else None},
         "stages_ms": {"layout_change": timers.total_ms("layout") / steps if C > 1 else None,
-                      "pass1_k1h_solve_and_level_histogram": k1h_ms, "pass2_k1_solve": k1_ms,
+                      "pass1_k1t_solve_and_level_histogram": k1h_ms, "pass2_k1_solve": k1_ms,
                       "pass2_k2_histogram (overlapped with k1)" if k1_n > 1 else "pass2_k2_histogram": k2_ms},
-        "roofline_k1h": {"bound": "hbm", "kernel": "k_quant_fast<count> (pass 1: no per-element output)",
+        "roofline_k1h": {"bound": "hbm", "kernel": "k_level_counts_hull (pass 1, K1t: thresholds instead of a lambda loop; no per-element output)",
                          "achieved": 8.0 * E / (k1h_ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": 8.0 * E / (k1h_ms * 1e-3) / HBM_PEAK, "algorithmic_bytes_per_launch": 8 * E,
                          "avg_launch_ms": k1h_ms, "latents_per_s_kernel_only": E * L / (k1h_ms * 1e-3),

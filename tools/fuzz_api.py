@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Randomized API fuzz of vbq_quantize_f32 / vbq_histogram_u16 against the C oracle: random shapes, layouts,
-bit depths, lambda counts (above the 32-lambda chunk too), raw / corrected lengths, optional outputs, lambdas
-outside the fast kernel's range, both arithmetic modes.   python tools/fuzz_api.py [--cases 300] [--seed 0]"""
+"""Randomized API fuzz of vbq_quantize_f32 / vbq_histogram_u16 / vbq_level_counts_f32 and the row-range forms against the C
+oracle: random shapes, layouts, bit depths, lambda counts (above the 32-lambda chunk too), raw / corrected lengths, optional
+outputs, lambdas outside the fast kernel's range, both arithmetic modes, random row cuts.
+    python tools/fuzz_api.py [--cases 300] [--seed 0]"""
 import argparse
 import os
 import sys
@@ -75,6 +76,29 @@ def one_case(rng, dev):
     hist = ops.histogram(got[0], C, N=N, layout=layout).cpu().numpy()
     hw = CO.histogram(want[0], C, N=N)
     miss += int((hist != hw).sum())
+    # the same pass cut into random row ranges (vbq_quantize_rows_f32 / vbq_histogram_rows_u16)
+    if mode == "f32" and rng.random() < 0.5:
+        cuts = sorted({0, rows, *[int(v) for v in rng.integers(0, rows + 1, 2)]})
+        idx2 = torch.zeros_like(got[0])
+        cnt2 = torch.zeros(hist.shape, dtype=torch.int64, device=dev)
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            ops.quantize(torch.from_numpy(m_in).to(dev), torch.from_numpy(s_in).to(dev), torch.from_numpy(tab).to(dev), list(lam), N=N,
+                         level_len=None if ll is None else torch.from_numpy(ll).to(dev), layout=layout, out_idx=idx2, rows=(a, b),
+                         workgroups_per_cu=int(rng.choice([0, 4])))
+            ops.histogram(idx2, C, N=N, layout=layout, out=cnt2, rows=(a, b))
+        miss += int((canon(idx2) != want[0]).sum()) + int((cnt2.cpu().numpy() != hw).sum())
+    # the counting kernels (K1t for raw lengths at N = 10, K1h otherwise): bit-length histogram of the same solve
+    in_range = bool(np.all((lam >= 1.9e-12) & (lam <= 1.8e19)))
+    if mode == "f32" and in_range and (C == 1 or layout == "cb" or rng.random() < 0.5):
+        lay = layout if (C == 1 or layout == "cb") else "bc->cb"
+        lc = ops.level_counts(torch.from_numpy(m_in).to(dev), torch.from_numpy(s_in).to(dev), torch.from_numpy(tab).to(dev), list(lam), N=N,
+                              level_len=None if ll is None else torch.from_numpy(ll).to(dev), layout=lay).cpu().numpy()
+        k = np.arange(1, T + 1)
+        lev = N - np.log2(k & -k).astype(np.int64)
+        wl = np.zeros((L, C, N + 1), np.int64)
+        for n in range(N + 1):
+            wl[:, :, n] = hw[:, :, lev == n].sum(axis=2)
+        miss += int((lc != wl).sum())
     desc = f"N={N} C={C} rows={rows} L={L} layout={layout} mode={mode} ll={ll is not None} zhat={wz} bits={wb}: {miss} mismatches"
     return (desc if miss else None), rows * C * L
 
