@@ -20,7 +20,7 @@ dst = os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
 
 KERNELS = ("k_level_counts_hull", "k_quant_fast", "k_hist_flat", "k_transpose", "k_prepare_penalties", "k_quant_tiled",
-           "k_quant_flat", "k_gather", "k_hist_tiled", "k_quant_notebook", "k_lut_lengths")
+           "k_quant_flat", "k_gather", "k_hist_tiled", "k_quant_notebook", "k_lut_lengths", "k_lut_models", "k_np_block_sums")
 
 
 def short(name):
@@ -121,8 +121,11 @@ if os.path.exists(bench):
     out["bench_line"] = json.loads(open(bench).read().strip().splitlines()[-1])
 json.dump(out, open(os.path.join(dst, f"{tag}_pmc.json"), "w"), indent=1)
 with open(os.path.join(dst, f"{tag}_summary.md"), "w") as f:
-    f.write(f"# rocprofv3 summary, tag `{tag}`\n\nCommand: `rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline` "
-            "(kernel times); `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` in separate passes (traffic).\n\n"
+    f.write(f"# rocprofv3 summary, tag `{tag}`\n\nCommands (`tools/profile_round.sh {tag}` on the GPU box): `rocprofv3 --output-format csv "
+            "--kernel-trace --stats -- python3 bench.py --no-cpu-baseline --no-other-workloads --no-graph --steps 9 --warmup 3` (kernel "
+            "times; eager launches so that every kernel is a trace record; the extra launches beyond steps + warm-up are the bench's own "
+            "parity checks), then the same command with `--pmc FETCH_SIZE`, `--pmc WRITE_SIZE` and two sets of eight SQ counters in "
+            "separate passes (`--kernel-trace` only next to `--pmc`).\n\n"
             "| kernel | calls | avg us | min us | % of GPU time | HBM read (2 x FETCH_SIZE) MB | HBM write MB |\n|---|---|---|---|---|---|---|\n")
     for k, e in out.items():
         if k == "bench_line":
