@@ -38,7 +38,11 @@ Pinning status (see tests/golden/README.md and DESIGN.md):
   interval search on padded grids, the candidate assembly and the two-pass entropy
   model build.  Their semantics are pinned indirectly: the 21-candidate solve
   built from them must equal the reference's exhaustive ``quantize_indep_dims``
-  over all 2047 code points (golden set G6).
+  over all 2047 code points: golden set G6 (every row x every lambda of G5) and G12
+  (tables with repeated float32 code points, inputs beyond the table and at the rim
+  of every level's grid).  The notebook's stages are additionally pinned as a CHAIN
+  (G13: float32 moment -> code book -> compress_coordinates -> entropy); the moment's
+  summation order is restated in oracle/vbq_oracle.c and pinned against np.sum itself.
 * PARITY UNPINNED: BMSHJ2018Prior numerics (TF kernels for matmul/softplus/tanh/
   sigmoid; no checkpoint, stored table or test in the reference fixes its output).
   Only self-consistency is tested.
