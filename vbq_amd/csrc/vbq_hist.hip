@@ -12,7 +12,10 @@
 namespace vbq {
 namespace {
 
-constexpr int kHistThreads = 256;
+#ifndef VBQ_HIST_THREADS
+#define VBQ_HIST_THREADS 256
+#endif
+constexpr int kHistThreads = VBQ_HIST_THREADS;
 #ifndef VBQ_HIST_U
 #define VBQ_HIST_U 2
 #endif
