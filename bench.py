@@ -282,7 +282,9 @@ def run_workload(name, args, torch, dist, dev, rank, world, steps, warmup, detai
                      "frac": alg_bytes / (k1_ms * 1e-3) / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_src,
                      "algorithmic_bytes_per_pass": alg_bytes, "launches_per_pass": k1_n,
                      "algorithmic_bytes_per_launch": alg_bytes / max(k1_n, 1), "avg_launch_ms": k1_ms / max(k1_n, 1),
-                     "pass_ms": k1_ms, "latents_per_s_kernel_only": E * L / (k1_ms * 1e-3), "valu": valu,
+                     "pass_ms": k1_ms, "latents_per_s_kernel_only": E * L / (k1_ms * 1e-3),
+                     # what actually bounds the kernel: share of the SIMDs' issue cycles spent on its VALU instructions
+                     "valu_issue_frac": (valu or {}).get("valu_issue_frac"), "valu": valu,
                      "note": "K2 of the previous row chunk runs concurrently on a second stream" if k1_n > 1 else None},
         "stages_ms": {"layout_change": timers.total_ms("layout") / steps if C > 1 else None,
                       "pass1_k1t_solve_and_level_histogram": k1h_ms, "pass2_k1_solve": k1_ms,
