@@ -441,6 +441,12 @@ k_quant_fast(const float *__restrict__ mu, const float *__restrict__ sg, long n_
 #ifndef VBQ_HULL_WAVES
 #define VBQ_HULL_WAVES 4
 #endif
+#ifndef VBQ_HULL_NE
+#define VBQ_HULL_NE 2
+#endif
+#ifndef VBQ_HULL_COPIES
+#define VBQ_HULL_COPIES 16
+#endif
 constexpr int kHullKeys = 2048;         // 16 octaves of 128 buckets
 // v_min_f32 / v_max_f32 as they are (IEEE mode: a NaN operand loses).  fminf / fmaxf make the compiler canonicalise
 // operands it cannot prove quiet (a v_max x, x in front of every second min of the threshold recurrences).
@@ -480,14 +486,15 @@ k_level_counts_hull(const float *__restrict__ mu, const float *__restrict__ sg, 
                     unsigned long long *__restrict__ level_counts, int dbg) {
     constexpr int T = table_size(N);
     constexpr int N1 = N + 1;
-    constexpr int NE = 2;
+    constexpr int NE = VBQ_HULL_NE;
+    constexpr int KC = VBQ_HULL_COPIES;                      // words per (level, position) counter; two 16-bit halves each
     constexpr int PS = (N1 + 3) & ~3;
     constexpr int LB = 33;                                    // positions 0..32
     __shared__ float tb[T + 1];
     __shared__ __align__(16) float penl[kMaxLambdaChunk * PS];
     __shared__ __align__(4) unsigned char lut[kHullKeys];
     __shared__ float4 rec[34];                                // rec[i] = { lam[i-1], lam[i], lam[i+1], - } with -big / +big outside
-    __shared__ unsigned int H[N * LB * 16];                   // [n][a][16 words x 2 halves]
+    __shared__ unsigned int H[N * LB * KC];                   // [n][a][16 words x 2 halves]
     __shared__ int corr[kMaxLambdaChunk * N1];
     __shared__ unsigned int n_valid;
     const int c = blockIdx.y;
@@ -497,7 +504,7 @@ k_level_counts_hull(const float *__restrict__ mu, const float *__restrict__ sg, 
         const int l = i / PS, n = i - l * PS;
         penl[i] = n < N1 ? pen[((long)l * C + c) * N1 + n] : 0.0f;
     }
-    for (int i = threadIdx.x; i < N * LB * 16; i += blockDim.x) H[i] = 0;
+    for (int i = threadIdx.x; i < N * LB * KC; i += blockDim.x) H[i] = 0;
     for (int i = threadIdx.x; i < L * N1; i += blockDim.x) corr[i] = 0;
     for (int b = threadIdx.x; b < kHullKeys / 4; b += blockDim.x)   // the bucket table travels in the kernel arguments
         reinterpret_cast<uint32_t *>(lut)[b] = reinterpret_cast<const uint32_t *>(sw.lut)[b];
@@ -514,8 +521,8 @@ k_level_counts_hull(const float *__restrict__ mu, const float *__restrict__ sg, 
     const long nquads = (n_per_ch + NE - 1) / NE;
     const char *tbb = reinterpret_cast<const char *>(tb);
     const unsigned int lane = threadIdx.x & 63u;
-    const unsigned int inc = (lane & 16u) ? 0x10000u : 1u;
-    const unsigned int copy = lane & 15u;
+    const unsigned int inc = (lane & (unsigned)KC) ? 0x10000u : 1u;
+    const unsigned int copy = lane & (unsigned)(KC - 1);
     unsigned int my_valid = 0;
 
     for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < nquads; q += (long)gridDim.x * blockDim.x) {
@@ -529,11 +536,11 @@ k_level_counts_hull(const float *__restrict__ mu, const float *__restrict__ sg, 
                 m4[k] = ok ? mu[(i0 + k) * C + c] : 0.0f;
                 s4[k] = ok ? sg[(i0 + k) * C + c] : 1.0f;
             }
-        } else if (full) {
+        } else if (full && NE == 2) {
             const float2 mv = *reinterpret_cast<const float2 *>(mu + base + i0);
             const float2 sv = *reinterpret_cast<const float2 *>(sg + base + i0);
-            m4[0] = mv.x; m4[1] = mv.y;
-            s4[0] = sv.x; s4[1] = sv.y;
+            m4[0] = mv.x; m4[NE - 1] = mv.y;
+            s4[0] = sv.x; s4[NE - 1] = sv.y;
         } else {
 #pragma unroll
             for (int k = 0; k < NE; ++k) {
@@ -622,7 +629,7 @@ k_level_counts_hull(const float *__restrict__ mu, const float *__restrict__ sg, 
                 const float dist = vmin3abs(__fsub_rn(t, nb.x), __fsub_rn(t, nb.y), __fsub_rn(t, nb.z));
                 near[n] = __builtin_amdgcn_ballot_w64(dist <= G);
                 any_near |= near[n];
-                atomicAdd(&H[((uint32_t)n * LB + a) * 16u + copy], vinc);      // padding lanes add 0: no exec juggling
+                atomicAdd(&H[((uint32_t)n * LB + a) * (unsigned)KC + copy], vinc);      // padding lanes add 0: no exec juggling
             }
             if (any_near != 0) {                               // rare: list the sweep points inside the band(s)
 #pragma unroll
@@ -667,8 +674,8 @@ k_level_counts_hull(const float *__restrict__ mu, const float *__restrict__ sg, 
     for (int i = threadIdx.x; i < N * LB; i += blockDim.x) {
         unsigned int v = 0;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const unsigned int w = H[i * 16 + j];
+        for (int j = 0; j < KC; ++j) {
+            const unsigned int w = H[i * KC + j];
             v += (w & 0xffffu) + (w >> 16);
         }
         hs[i] = v;
@@ -774,10 +781,10 @@ int launch_level_counts_hull10(const float *mu, const float *sg, int64_t n_per_c
             sw.lut[b] = (unsigned char)l;
         }
     }
-    const int64_t nquads = (n_per_ch + 1) / 2;
+    const int64_t nquads = (n_per_ch + VBQ_HULL_NE - 1) / VBQ_HULL_NE;
     int64_t gx = (nquads + kFastThreads - 1) / kFastThreads;
     static const int rounds = [] { const char *e = getenv("VBQ_HULL_ROUNDS"); return e ? atoi(e) : 1; }();
-    int64_t cap = (int64_t)256 * 4 * rounds / n_ch;          // 4 workgroups per CU resident (35 KB of LDS each)
+    int64_t cap = (int64_t)256 * VBQ_HULL_WAVES * rounds / n_ch;          // VBQ_HULL_WAVES workgroups per CU resident
     if (cap < 1) cap = 1;
     if (gx > cap) {
         const int64_t iters = gx;
@@ -787,7 +794,9 @@ int launch_level_counts_hull10(const float *mu, const float *sg, int64_t n_per_c
             if (pad * best < best_pad * g) { best = g; best_pad = pad; }
         }
         gx = best;
-        if ((iters + gx - 1) / gx > 4000) gx = (iters + 3999) / 4000;     // 16-bit partial counters
+        // 16-bit partial counters: a half takes at most (32 / copies) lanes x 4 waves x NE per iteration
+        const int64_t max_iters = 65000 / ((32 / VBQ_HULL_COPIES) * 4 * VBQ_HULL_NE);
+        if ((iters + gx - 1) / gx > max_iters) gx = (iters + max_iters - 1) / max_iters;
     }
     static const int dbg = [] { const char *e = getenv("VBQ_FAST_DEBUG"); return e ? atoi(e) : 0; }();
     hipLaunchKernelGGL((k_level_counts_hull<10>), dim3((unsigned)gx, (unsigned)n_ch), dim3(kFastThreads), 0, st, mu, sg,
