@@ -277,6 +277,8 @@ def moments(x: torch.Tensor, *, layout="bc", out: Optional[torch.Tensor] = None)
 def numpy_sum_sq(x: torch.Tensor) -> torch.Tensor:
     """vbq_numpy_sum_sq_f32: np.sum(x.ravel()**2) of a float32 tensor in NumPy's own summation order -> f32 [1] (device)."""
     x = _dev(x, torch.float32, "x").reshape(-1)
+    if x.data_ptr() % 16:                       # a view into a larger tensor: the block kernel loads 16 bytes per lane
+        x = x.clone()
     out = torch.zeros(1, dtype=torch.float32, device=x.device)
     h = _lib.lib()
     wsb = h.vbq_numpy_sum_sq_workspace_bytes(x.numel())
