@@ -277,6 +277,8 @@ def run_workload(name, args, torch, dist, dev, rank, world, steps, warmup, detai
         "ms_per_step": dt / steps * 1e3,
         "value": world * 2 * E * L * steps / dt,
         "solves_per_step": 2 * E * L,
+        # the same throughput counting every (element, lambda) pair once per build instead of once per pass
+        "pairs_per_s": world * E * L * steps / dt,
         "roofline": {"bound": "hbm", "kernel": "k_quant_fast (pass 2: corrected lengths -> rank indices)",
                      "achieved": alg_bytes / (k1_ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                      "frac": alg_bytes / (k1_ms * 1e-3) / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_src,
@@ -458,6 +460,8 @@ def main():
             "data": "synthetic",
             "config": res["config"],
             "roofline": res["roofline"],
+            "solves_per_step": res["solves_per_step"],
+            "pairs_per_s": res["pairs_per_s"],
             "stages_ms": res["stages_ms"],
             "roofline_k1h": res["roofline_k1h"],
             "roofline_k2_histogram": res["roofline_k2_histogram"],
