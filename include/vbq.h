@@ -120,6 +120,12 @@ int vbq_quantize_f32(const float *d_mu, const float *d_sigma, int64_t n_rows, in
                      uint16_t *d_out_idx, float *d_out_zhat, float *d_out_bits,
                      void *d_workspace, size_t workspace_bytes, void *stream);
 
+/* ChannelwisePriorCDFQuantizer.get_all_N_bit_intervals (quantizer.py:65-80) as a result of its own (API compatibility; the
+ * solve never materialises it): d_left / d_right f32 [n_ch][N+1][n_rows] = the left / right n-bit neighbours of every
+ * z on every level, edge padding of the per-level grids included (:54-57,75-76).  d_z_cb: planes [n_ch][n_rows]. */
+int vbq_n_bit_intervals_f32(const float *d_z_cb, int64_t n_rows, int32_t n_ch, const float *d_table_lm, int32_t N,
+                            float *d_left, float *d_right, void *stream);
+
 /* The same solve on rows [row_begin, row_end) of the full arrays (pointers, n_rows and output addressing are those
  * of the whole tensor): lets the caller cut one pass into chunks and run K2 on chunk j (another stream) while K1
  * works on chunk j + 1.  workgroups_per_cu = 0: default grid; 1..5: a persistent grid of that many workgroups per

@@ -439,6 +439,9 @@ def test_g12_duplicates_and_edges_on_gpu(golden):
     Zd, Bd = q.compress_batch_channel_latents(g["mu"], g["sigma"], lam)
     for i, l in enumerate(lam):
         assert np.array_equal(Zd[l], g["zhat"][i]) and np.array_equal(Bd[l], g["bits"][i])
+    left, right = q.get_all_N_bit_intervals(g["mu"])                  # repeated points and the rims of every level's grid
+    lo, ro = O.get_all_N_bit_intervals(q._search_grids, g["mu"])
+    assert np.array_equal(left.cpu().numpy(), lo) and np.array_equal(right.cpu().numpy(), ro)
 
 
 def test_g13_notebook_chain_on_gpu(golden):

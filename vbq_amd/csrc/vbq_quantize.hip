@@ -324,6 +324,47 @@ k_quant_tiled(const float *__restrict__ mu, const float *__restrict__ sg, long n
     }
 }
 
+// ChannelwisePriorCDFQuantizer.get_all_N_bit_intervals (quantizer.py:65-80) as a result of its own: the left / right n-bit
+// neighbours of every z on every level, [C][N+1][B] each -- what the reference materialises before its solve and K1 never does.
+// One channel per blockIdx.y (planes), same descent as every other kernel of this file.
+template <int N>
+__global__ void __launch_bounds__(256)
+k_intervals(const float *__restrict__ z_cb, long n_rows, const float *__restrict__ table, float *__restrict__ left,
+            float *__restrict__ right) {
+    constexpr int T = table_size(N);
+    __shared__ float tb[T + 1];
+    const int c = blockIdx.y;
+    for (int i = threadIdx.x; i < T; i += blockDim.x) tb[i] = table[(long)c * T + i];
+    __syncthreads();
+    for (long b = (long)blockIdx.x * blockDim.x + threadIdx.x; b < n_rows; b += (long)gridDim.x * blockDim.x) {
+        const float z = z_cb[(long)c * n_rows + b];
+        uint32_t g = 0;
+#pragma unroll
+        for (int n = 0; n <= N; ++n) {
+            const int off = (1 << n) - 1;
+            const int m = 1 << n;
+            const uint32_t j = g;
+            const float pj = tb[off + j];
+            const bool below = pj < z;
+            float l = pj, r = pj;
+            if (n > 0) {
+                int jo = below ? (int)j + 1 : (int)j - 1;
+                jo = jo < 0 ? 0 : (jo > m - 1 ? m - 1 : jo);
+                bool swap = false;
+                if (n == N && below && j == (uint32_t)(m - 1)) { jo = m - 2; swap = true; }     // no edge padding on the deepest level
+                const float po = tb[off + jo];
+                const bool j_is_left = below && !swap;
+                l = j_is_left ? pj : po;
+                r = j_is_left ? po : pj;
+            }
+            const long o = ((long)c * (N + 1) + n) * n_rows + b;
+            left[o] = l;
+            right[o] = r;
+            g = 2 * g + (below ? 1u : 0u);
+        }
+    }
+}
+
 // VBQ_PLAIN_KERNEL=1 routes everything through the literal 21-candidate kernels (A/B checks).
 inline bool force_plain_kernel() {
     static const bool v = [] { const char *e = getenv("VBQ_PLAIN_KERNEL"); return e && e[0] == '1'; }();
@@ -534,4 +575,30 @@ extern "C" int vbq_level_counts_f32(const float *d_mu, const float *d_sigma, int
     return quantize_entry("vbq_level_counts_f32", d_mu, d_sigma, n_rows, n_ch, layout, d_table_lm, d_level_len, h_lambdas,
                           n_lambda, N, VBQ_MODE_F32, nullptr, nullptr, nullptr, d_workspace, workspace_bytes, 0, n_rows,
                           reinterpret_cast<unsigned long long *>(d_level_counts), 0, stream);
+}
+
+extern "C" int vbq_n_bit_intervals_f32(const float *d_z_cb, int64_t n_rows, int32_t n_ch, const float *d_table_lm, int32_t N,
+                                       float *d_left, float *d_right, void *stream) {
+    using namespace vbq;
+    VBQ_REQUIRE(n_rows >= 0 && n_ch >= 1 && n_ch <= 65535, VBQ_ERR_INVALID_ARGUMENT, "vbq_n_bit_intervals_f32: bad sizes");
+    if (n_rows == 0) return VBQ_OK;
+    VBQ_REQUIRE(d_z_cb && d_table_lm && d_left && d_right, VBQ_ERR_INVALID_ARGUMENT, "vbq_n_bit_intervals_f32: null pointer argument");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    int64_t gx = (n_rows + 255) / 256;
+    const int64_t cap = 2048 / n_ch + 1;
+    if (gx > cap) gx = cap;
+#define VBQ_DISPATCH_N(NN)                                                                                              \
+    case NN:                                                                                                            \
+        hipLaunchKernelGGL((k_intervals<NN>), dim3((unsigned)gx, (unsigned)n_ch), dim3(256), 0, st, d_z_cb, (long)n_rows, \
+                           d_table_lm, d_left, d_right);                                                                \
+        break;
+    switch (N) {
+        VBQ_FOR_EACH_N(VBQ_DISPATCH_N)
+        default:
+            set_error("vbq_n_bit_intervals_f32: max_bits_per_coord N=%d not built", N);
+            return VBQ_ERR_UNSUPPORTED;
+    }
+#undef VBQ_DISPATCH_N
+    VBQ_CHECK_LAUNCH("n_bit_intervals");
+    return VBQ_OK;
 }

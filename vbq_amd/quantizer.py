@@ -174,15 +174,19 @@ class ChannelwisePriorCDFQuantizer:
 
     # ------------------------------------------------------------------ compat helper (quantizer.py:65-80)
     def get_all_N_bit_intervals(self, Z):
-        """Left/right n-bit neighbours, C x (N+1) x B.  Kept for API compatibility only: the
-        solve below never materialises these tensors."""
+        """Left/right n-bit neighbours, C x (N+1) x B (device tensors).  Kept for API compatibility only: the
+        solve below never materialises these tensors (vbq_n_bit_intervals_f32)."""
+        from . import _lib
         Zt = torch.as_tensor(_to_numpy(Z) if not isinstance(Z, torch.Tensor) else Z, dtype=torch.float32).to(self.device)
-        grids = self._dev("grids", lambda: torch.from_numpy(self._search_grids))
-        G = grids.shape[-1]
-        zr = Zt.t().contiguous()[:, None, :].expand(-1, grids.shape[1], -1).contiguous()
-        r = torch.searchsorted(grids, zr, right=False).clamp_(0, G - 1)
-        l = (r - 1).clamp_(0, G - 1)
-        return torch.gather(grids, 2, l), torch.gather(grids, 2, r)
+        if Zt.dim() != 2 or Zt.shape[1] != self.num_channels:
+            raise ValueError(f"expected Z of shape [B, {self.num_channels}], got {tuple(Zt.shape)}")
+        z_cb = ops.transpose(Zt.contiguous())                                       # [C, B] (quantizer.py:73)
+        C, B, N = self.num_channels, Zt.shape[0], self.max_bits_per_coord
+        left = torch.empty((C, N + 1, B), dtype=torch.float32, device=self.device)
+        right = torch.empty_like(left)
+        _lib.check(_lib.lib().vbq_n_bit_intervals_f32(ops._ptr(z_cb), B, C, ops._ptr(self._table_dev()), N, ops._ptr(left),
+                                                      ops._ptr(right), ops._stream(z_cb)), "vbq_n_bit_intervals_f32")
+        return left, right
 
     # ------------------------------------------------------------------ the solve
     def _prep(self, batch_means, batch_stds):
