@@ -234,6 +234,16 @@ int vbq_histogram_rows_u16(const uint16_t *d_idx, int64_t n_rows, int32_t n_ch, 
                            int32_t n_lambda, int32_t N, void *d_counts, int32_t counts_are_i32,
                            int64_t row_begin, int64_t row_end, void *stream);
 
+/* K2 as the LAST stage of the build: counts := histogram of the planes d_idx [n_lambda][n_ch][n_rows] (ASSIGNED, not added:
+ * no zeroing beforehand) and, when d_models is given, models[l][c][q] = lut[counts[l][c][q]] -- the code-length table of
+ * quantizer.py:141-146 in its tabulated form (see vbq_code_lengths_from_counts).  With at least 2048 (lambda, channel) rows
+ * one workgroup owns each row, stores its bins and looks the lengths up in the same flush (no memset of the count array, no
+ * atomics, no separate pass over it); smaller problems are composed from the plain entry points.  Single-GPU form: sharded
+ * builds all-reduce the counts first and then call vbq_code_lengths_from_counts. */
+int vbq_histogram_models_u16(const uint16_t *d_idx, int64_t n_rows, int32_t n_ch, int32_t n_lambda, int32_t N,
+                             void *d_counts, int32_t counts_are_i32, const float *d_lut, int64_t lut_n,
+                             float *d_models, void *stream);
+
 /* Largest index of a u16 index array (d_max: u32, device, MAX-ed into; zero it first).  K2 and the gather are
  * memory-safe for any u16 input (indices >= T are counted in a wrapped bin / read the last table entry); a
  * caller holding indices that did not come from K1 (a file, a decoder) checks max < T with this first. */

@@ -231,3 +231,24 @@ def test_code_lengths_from_counts_match_numpy(ops):
             assert np.array_equal(ln.cpu().numpy(), (lv + want_model).astype(np.float32))
     assert entropy.neg_log2_lut(1 << 24, T, 1) is None                                  # sums no longer exact in f32
     assert entropy.neg_log2_lut(1000, T, 0.5) is None                                   # non-integer smoothing
+
+
+@pytest.mark.parametrize("rows,C,L,dt", [(3001, 70, 32, torch.int32), (512, 2048, 1, torch.int64), (1000, 5, 3, torch.int32),
+                                         (8, 64, 32, torch.int64)])
+def test_histogram_models_assigns_counts_and_lengths(ops, rows, C, L, dt):
+    """vbq_histogram_models_u16, fused (>= 2048 rows of bins: one workgroup per row stores its bins and the looked-up lengths)
+    and composed (smaller problems): counts are ASSIGNED (stale contents of the buffer must not survive), models = lut[counts]."""
+    from vbq_amd import entropy
+    rng = np.random.default_rng(rows + C)
+    idx = torch.from_numpy(rng.integers(0, T, (L, C, rows)).astype(np.uint16)).cuda()
+    idx[:, :, : rows // 2] = 1023                                      # a hot bin
+    want = ops.histogram(idx, C, N=N, layout="cb")
+    lut = entropy.neg_log2_lut(rows, T, 1)
+    counts = torch.full((L, C, T), 12345, dtype=dt, device="cuda")
+    models = torch.full((L, C, T), -1.0, dtype=torch.float32, device="cuda")
+    ops.histogram_models(idx, C, counts, N=N, lut=torch.from_numpy(lut).cuda(), models=models)
+    assert torch.equal(counts.to(torch.int64), want)
+    assert np.array_equal(models.cpu().numpy(), entropy.neg_log2_freq(want, 1))
+    counts2 = torch.full((L, C, T), 7, dtype=dt, device="cuda")
+    ops.histogram_models(idx, C, counts2, N=N)                         # counts only
+    assert torch.equal(counts2.to(torch.int64), want)

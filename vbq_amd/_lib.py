@@ -50,6 +50,8 @@ SIGNATURES = {
                                     C.c_void_p]),
     "vbq_histogram_u16_i32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                         C.c_void_p, C.c_void_p]),
+    "vbq_histogram_models_u16": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
+                                           C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "vbq_index_max_u16": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "vbq_moments_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "vbq_numpy_sum_sq_workspace_bytes": (C.c_size_t, [C.c_int64]),

@@ -79,10 +79,14 @@ __device__ __forceinline__ void hist_add8(unsigned int *h, const uint4 v) {
 }
 
 // All indices of the workgroup belong to one channel: [l][c][n_per_ch] contiguous.
+// assign_lut != nullptr (only with ONE workgroup per (lambda, channel), gridDim.x == 1): the workgroup owns its whole row of
+// bins, so it STORES them (zeros included: no memset of the 67 MB array beforehand, no atomics) and writes the code-length
+// model lut[count] next to them (quantizer.py:141-146 fused into the flush; models may be nullptr).
 template <int N, typename CountT>
 __global__ void __launch_bounds__(kHistThreads)
 k_hist_flat(const uint16_t *__restrict__ idx, long n_per_ch, long ch_stride, int C, long E,
-            CountT *__restrict__ counts, int vec_ok) {
+            CountT *__restrict__ counts, int vec_ok, int assign = 0, const float *__restrict__ assign_lut = nullptr,
+            long lut_n = 0, float *__restrict__ models = nullptr) {
     constexpr int T = table_size(N);
     constexpr int kHistCopies = hist_copies(T);
     static_assert(T + 1 <= 8192, "bins are laid out for at most 8192 slots");
@@ -152,7 +156,12 @@ k_hist_flat(const uint16_t *__restrict__ idx, long n_per_ch, long ch_stride, int
         } else {
             v = h[bin_slot<N>(i)];
         }
-        if (v) atomicAdd(&dst[i], (CountT)v);
+        if (assign) {
+            dst[i] = (CountT)v;
+            if (models) models[((long)l * C + c) * T + i] = assign_lut[(long)v < lut_n ? (long)v : lut_n - 1];
+        } else if (v) {
+            atomicAdd(&dst[i], (CountT)v);
+        }
     }
 }
 
@@ -484,6 +493,62 @@ extern "C" int vbq_histogram_rows_u16(const uint16_t *d_idx, int64_t n_rows, int
                                                   reinterpret_cast<unsigned int *>(d_counts), row_begin, row_end, stream);
     return vbq::histogram_entry<unsigned long long>("vbq_histogram_rows_u16", d_idx, n_rows, n_ch, layout, n_lambda, N,
                                                     reinterpret_cast<unsigned long long *>(d_counts), row_begin, row_end, stream);
+}
+
+namespace vbq {
+namespace {
+template <int N, typename CountT>
+int launch_hist_assign(const uint16_t *idx, int64_t n_rows, int32_t n_ch, int32_t L, CountT *counts, const float *lut,
+                       int64_t lut_n, float *models, hipStream_t st) {
+    const int64_t E = n_rows * (int64_t)n_ch;
+    const int vec_ok = (reinterpret_cast<uintptr_t>(idx) % 16 == 0) && (n_rows % 8 == 0 || (n_ch == 1 && L == 1)) && (E % 8 == 0 || L == 1);
+    hipLaunchKernelGGL((k_hist_flat<N, CountT>), dim3(1u, (unsigned)n_ch, (unsigned)L), dim3(kHistThreads), 0, st, idx, (long)n_rows,
+                       (long)n_rows, (int)n_ch, (long)E, counts, vec_ok, 1, lut, (long)lut_n, models);
+    VBQ_CHECK_LAUNCH("hist_assign");
+    return VBQ_OK;
+}
+}  // namespace
+}  // namespace vbq
+
+extern "C" int vbq_histogram_models_u16(const uint16_t *d_idx, int64_t n_rows, int32_t n_ch, int32_t n_lambda, int32_t N,
+                                        void *d_counts, int32_t counts_are_i32, const float *d_lut, int64_t lut_n,
+                                        float *d_models, void *stream) {
+    using namespace vbq;
+    VBQ_REQUIRE(n_rows >= 0 && n_ch >= 1 && n_lambda >= 1 && n_lambda <= 65535 && n_ch <= 65535, VBQ_ERR_INVALID_ARGUMENT,
+                "vbq_histogram_models_u16: bad sizes n_rows=%lld n_ch=%d n_lambda=%d", (long long)n_rows, n_ch, n_lambda);
+    VBQ_REQUIRE(d_idx && d_counts && (!d_models || (d_lut && lut_n >= 1)), VBQ_ERR_INVALID_ARGUMENT,
+                "vbq_histogram_models_u16: null pointer argument");
+    VBQ_REQUIRE(!counts_are_i32 || n_rows <= 0x7fffffffLL, VBQ_ERR_INVALID_ARGUMENT,
+                "vbq_histogram_models_u16: %lld rows per channel can overflow 32-bit counters", (long long)n_rows);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int64_t n_bins = (int64_t)n_lambda * n_ch * table_size(N);
+    // one workgroup per (lambda, channel) is the launch shape of the plain histogram whenever there are at least 2048 rows of
+    // bins (cap = 2048 / (C L) + 1 = 1): then the fused form applies; otherwise compose it from the plain entry points
+    const bool fused = (int64_t)n_ch * n_lambda >= 2048 && N >= 4 && N <= 12 && n_rows > 0;
+    if (fused) {
+#define VBQ_DISPATCH_N(NN)                                                                                                   \
+    case NN:                                                                                                                 \
+        return counts_are_i32 ? launch_hist_assign<NN, unsigned int>(d_idx, n_rows, n_ch, n_lambda,                          \
+                                                                     reinterpret_cast<unsigned int *>(d_counts), d_lut, lut_n, \
+                                                                     d_models, st)                                           \
+                              : launch_hist_assign<NN, unsigned long long>(d_idx, n_rows, n_ch, n_lambda,                    \
+                                                                           reinterpret_cast<unsigned long long *>(d_counts), \
+                                                                           d_lut, lut_n, d_models, st);
+        switch (N) {
+            VBQ_FOR_EACH_N(VBQ_DISPATCH_N)
+            default: break;
+        }
+#undef VBQ_DISPATCH_N
+        set_error("vbq_histogram_models_u16: max_bits_per_coord N=%d not built", N);
+        return VBQ_ERR_UNSUPPORTED;
+    }
+    if (hipMemsetAsync(d_counts, 0, (size_t)n_bins * (counts_are_i32 ? 4 : 8), st) != hipSuccess) {
+        set_error("vbq_histogram_models_u16: hipMemsetAsync failed");
+        return VBQ_ERR_LAUNCH;
+    }
+    int r = vbq_histogram_rows_u16(d_idx, n_rows, n_ch, VBQ_LAYOUT_CB, n_lambda, N, d_counts, counts_are_i32, 0, n_rows, stream);
+    if (r != VBQ_OK || !d_models) return r;
+    return vbq_code_lengths_from_counts(d_counts, counts_are_i32, n_bins, d_lut, lut_n, 0, nullptr, d_models, stream);
 }
 
 extern "C" int vbq_code_lengths_from_counts(const void *d_counts, int32_t counts_are_i32, int64_t n,

@@ -254,6 +254,29 @@ def histogram(idx: torch.Tensor, n_ch: int, *, N: int = 10, layout="bc", out: Op
     return out
 
 
+def histogram_models(idx: torch.Tensor, n_ch: int, counts: torch.Tensor, *, N: int = 10, lut: Optional[torch.Tensor] = None,
+                     models: Optional[torch.Tensor] = None):
+    """vbq_histogram_models_u16: counts[L, C, T] := histogram of the planes idx [L, C, rows] (assigned, not added) and, with
+    `lut` / `models` (f32 [L, C, T]), models := lut[counts] in the same pass.  Returns (counts, models)."""
+    idx = _dev(idx, torch.uint16, "idx")
+    if idx.dim() != 3 or idx.shape[1] != n_ch:
+        raise ValueError(f"idx must be planes [L, {n_ch}, rows], got {tuple(idx.shape)}")
+    L, _, rows = idx.shape
+    T = table_size(N)
+    if counts.dtype not in (torch.int64, torch.int32) or tuple(counts.shape) != (L, n_ch, T) or not counts.is_cuda or not counts.is_contiguous():
+        raise ValueError(f"counts: expected a contiguous int32 / int64 device tensor of shape {(L, n_ch, T)}")
+    if (lut is None) != (models is None):
+        raise ValueError("lut and models go together")
+    if models is not None:
+        lut = _dev(lut, torch.float32, "lut")
+        if models.dtype != torch.float32 or tuple(models.shape) != (L, n_ch, T) or not models.is_cuda or not models.is_contiguous():
+            raise ValueError(f"models: expected a contiguous f32 device tensor of shape {(L, n_ch, T)}")
+    check(_lib.lib().vbq_histogram_models_u16(_ptr(idx), rows, n_ch, L, N, _ptr(counts), int(counts.dtype == torch.int32), _ptr(lut),
+                                              lut.numel() if lut is not None else 0, _ptr(models), _stream(idx)),
+          "vbq_histogram_models_u16")
+    return counts, models
+
+
 def index_max(idx: torch.Tensor) -> int:
     """vbq_index_max_u16: the largest index of a u16 array (synchronises).  For indices of foreign origin: K2 and
     gather are memory-safe for anything, but only indices < T are meaningful."""

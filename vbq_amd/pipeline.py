@@ -135,8 +135,21 @@ class EntropyModelBuild:
             self._slot ^= 1
             self.counts = self._counts2[self._slot]
         self.wait(self._slot)                 # the all-reduce that last used this buffer
-        self.counts.zero_()
         main = torch.cuda.current_stream(self.dev)
+        self._models_current = False
+        if self.side is None and self.world == 1 and self.models is not None:
+            # one GPU: K2 owns whole rows of bins, so it assigns them (no zeroing of the 67 MB array) and looks the
+            # code lengths up in the same flush (quantizer.py:141-146)
+            self._t("k1", 0)
+            ops.quantize(mu_cb, sg_cb, self.table, self.lambdas, N=self.N, level_len=level_len, layout="cb",
+                         out_idx=self.idx, workspace=self.ws)
+            self._t("k1", 1)
+            self._t("k2", 0)
+            ops.histogram_models(self.idx, self.C, self.counts, N=self.N, lut=self.lut2, models=self.models)
+            self._t("k2", 1)
+            self._models_current = True
+            return self.idx, self.counts
+        self.counts.zero_()
         if self.side is None:
             self._t("k1", 0)
             ops.quantize(mu_cb, sg_cb, self.table, self.lambdas, N=self.N, level_len=level_len, layout="cb",
@@ -184,6 +197,8 @@ class EntropyModelBuild:
         self.wait(self._slot)
         if self.lut2 is None:
             return None
+        if getattr(self, "_models_current", False):       # K2 wrote them in its flush
+            return self.models
         ops._lib.check(ops._lib.lib().vbq_code_lengths_from_counts(
             ops._ptr(self.counts), int(self.counts.dtype == torch.int32), self.counts.numel(), ops._ptr(self.lut2),
             self.lut2.numel(), 0, None, ops._ptr(self.models), ops._stream(self.counts)), "vbq_code_lengths_from_counts")
