@@ -1,0 +1,110 @@
+"""The N > 1 path on REAL multi-GPU hardware (RCCL over xGMI): these tests enable themselves when at least two GPUs are visible
+(the driver's 8-GPU node) and skip on one-GPU boxes.  They sort last on purpose: nothing after them depends on them.
+On one GPU the same code paths are covered by tests/test_gpu_dist.py (two ranks over gloo, RCCL with one rank, the C-ABI
+communicator with one rank, bench.py --gpus 2 as the driver launches it).
+Children are fresh interpreters (spawn) that pick their GPU before any other HIP call; the parent only COUNTS devices."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+import torch.multiprocessing as mp
+
+from test_gpu_dist import LAMBS, N, ROOT, _build, _data, _run_cabi_comm
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.timeout(600)
+def test_cabi_communicator_two_gpus(tmp_path):
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (runs on the driver's 8-GPU node)")
+    _run_cabi_comm(2, tmp_path)
+
+
+def _nccl_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(rank)                                     # before any other HIP call
+    dev = torch.device("cuda", rank)
+    import torch.distributed as dist
+    from vbq_amd import dist as vd
+    from vbq_amd.dist import CountsAllReduce
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    res = {}
+    # (1) the quantizer's sharded build: every rank must end with the single-process models
+    scale, mu, sg = _data()
+    a, b = vd.shard_rows(mu.shape[0], rank, world)
+    q = _build(mu[a:b], sg[a:b], scale, group=dist.group.WORLD)
+    res["raw"] = {l: q.raw_code_length_entropy_models[l] for l in LAMBS}
+    res["full"] = {l: q.entropy_models[l] for l in LAMBS}
+    # (2) packed and plain counter reduces, asynchronous, on RCCL
+    rng = np.random.default_rng(100 + rank)
+    red_out = []
+    for limit in (1000, 1 << 22):
+        c = torch.from_numpy(rng.integers(0, 400, (3, 4, 2047)).astype(np.int32)).to(dev)
+        red = CountsAllReduce(c.numel(), dev, max_global_count=limit)
+        red.start(c).wait(check=True)
+        torch.cuda.synchronize()
+        red_out.append((red.packed, c.cpu().numpy()))
+    res["reduce"] = red_out
+    # (3) the bench's pipeline object, two steps back to back (double-buffered asynchronous reduce + second communicator)
+    from vbq_amd import ops
+    from vbq_amd.pipeline import EntropyModelBuild
+    tab = torch.from_numpy(q.all_code_points).to(dev)
+    mu_cb, sg_cb = ops.transpose(torch.from_numpy(mu[a:b]).to(dev)), ops.transpose(torch.from_numpy(sg[a:b]).to(dev))
+    build = EntropyModelBuild(b - a, mu.shape[1], LAMBS, tab, N=N, global_rows=mu.shape[0], distributed=True,
+                              level_group=dist.new_group())
+    for _ in range(2):
+        build.run(mu_cb, sg_cb)
+    build.wait()
+    torch.cuda.synchronize()
+    for r in build.reducers:
+        if r is not None:
+            r.check()
+    res["pipe_counts"] = build.counts.cpu().numpy().astype(np.int64)
+    res["pipe_levels"] = build.level_counts.cpu().numpy()
+    out.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_rccl_build_equals_single_process():
+    """The N > 1 path on the real transport: two ranks, two GPUs, RCCL.  Skips on one-GPU boxes; runs on the driver's
+    8-GPU node."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (runs on the driver's 8-GPU node)")
+    import torch.distributed as dist
+    if not dist.is_nccl_available():
+        pytest.skip("torch.distributed was built without the nccl (RCCL) backend")
+    scale, mu, sg = _data()
+    ref = _build(mu, sg, scale)
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = 29600 + os.getpid() % 100
+    procs = [ctx.Process(target=_nccl_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(out.get(timeout=400) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    gens = [np.random.default_rng(100 + r) for r in range(2)]
+    draws = [[g.integers(0, 400, (3, 4, 2047)).astype(np.int32) for _ in range(2)] for g in gens]
+    from vbq_amd import ops
+    from oracle import c_oracle as CO
+    for r in range(2):
+        for l in LAMBS:
+            assert np.array_equal(res[r]["raw"][l], ref.raw_code_length_entropy_models[l])
+            assert np.array_equal(res[r]["full"][l], ref.entropy_models[l])
+        assert res[r]["reduce"][0][0] is True and res[r]["reduce"][1][0] is False
+        for i in range(2):
+            assert np.array_equal(res[r]["reduce"][i][1], draws[0][i] + draws[1][i])
+        assert np.array_equal(res[r]["pipe_counts"], np.stack([ref._code_counts[l] for l in LAMBS]))
+    assert np.array_equal(res[0]["pipe_levels"], res[1]["pipe_levels"]) and res[0]["pipe_levels"].sum() == len(LAMBS) * mu.size
+
+
