@@ -384,3 +384,24 @@ def test_channel_last_in_planes_out(ops, rows, C):
         ops.quantize(dev(mu), dev(sg), dev(orc.all_code_points), [0.0, 1.0], N=N, layout="bc->cb")
     with pytest.raises(VBQError, match="fast f32 kernel"):
         ops.quantize(dev(mu), dev(sg), dev(orc.all_code_points), lam, N=N, layout="bc->cb", mode="f64")
+
+
+def test_caller_length_tables_outside_the_certificate_range(ops):
+    """vbq.h: a caller-supplied length table may make lambda * len tiny (below 2^-39) or huge; the fast kernel's tie
+    certificate does not cover that, so the workgroup that sees such a penalty takes its literal scan.  Same answers as the
+    oracle, for the index kernel and the counting kernel, with the odd values in one channel only."""
+    rng = np.random.default_rng(77)
+    rows, C = 3000, 3
+    tab, mu, sg = synth(rng, rows, C)
+    lam = [2.0 ** -8, 0.05, 1.0, 37.0]
+    ll = (np.arange(N + 1, dtype=np.float32)[None, None, :] + rng.uniform(0, 4, (len(lam), C, N + 1)).astype(np.float32)).astype(np.float32)
+    ll[0, 1, 3] = np.float32(1e-30)                                  # lambda * len = 4e-33: far below 2^-39
+    ll[2, 1, 7] = np.float32(3e30)                                   # lambda * len = 3e30: above 2^70
+    ll[3, 1, 0] = np.float32(0.0)                                    # exactly zero is inside the range
+    want = CO.quantize(mu, sg, tab, lam, N=N, level_len=ll, threads=8)
+    got = ops.quantize(dev(mu.T), dev(sg.T), dev(tab), lam, N=N, level_len=dev(ll), layout="cb")
+    assert np.array_equal(host(got).transpose(0, 2, 1), want)
+    lc = ops.level_counts(dev(mu.T), dev(sg.T), dev(tab), lam, N=N, level_len=dev(ll), layout="cb")
+    lev = O.levels_of_sorted_ranks(N)[want]
+    wl = np.stack([[np.bincount(lev[l, :, c], minlength=N + 1) for c in range(C)] for l in range(len(lam))])
+    assert np.array_equal(host(lc), wl)

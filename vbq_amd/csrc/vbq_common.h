@@ -56,7 +56,7 @@ __device__ __forceinline__ float neg_half_sq_err(float P, float mu, float sigma)
 template <int N>
 int launch_quant_fast(const float *mu, const float *sg, int64_t n_per_ch, int64_t ch_stride, int32_t n_ch, const float *table,
                       const float *pen, const float *len, int32_t L, uint16_t *out_idx, float *out_zhat,
-                      float *out_bits, int64_t E, int vec_ok, const unsigned int *odd_pen,
+                      float *out_bits, int64_t E, int vec_ok,
                       unsigned long long *level_counts, int wg_per_cu, hipStream_t st);
 
 // K1t (vbq_quantize_fast.hip): first entropy-model pass without a per-lambda loop; N = 10, raw lengths.  Returns 1 when the

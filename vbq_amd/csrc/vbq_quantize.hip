@@ -135,12 +135,9 @@ struct LambdaChunk {
     double lam[kMaxLambdaChunk];
 };
 
-// *odd (u32 in the workspace, zeroed per call) is raised when a caller-supplied length table yields a penalty
-// outside {0} U [2^-39, 2^70]: the fast kernel's tie certificate assumes that range, so it then sends every
-// solve through its literal scan (same answers, slower) instead of trusting a precondition it cannot see.
 template <typename T>
 __global__ void k_prepare_penalties(LambdaChunk lc, int L, int C, int N1, const float *__restrict__ level_len,
-                                    T *__restrict__ pen, unsigned int *__restrict__ odd) {
+                                    T *__restrict__ pen) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int total = L * C * N1;
     if (i >= total) return;
@@ -149,9 +146,7 @@ __global__ void k_prepare_penalties(LambdaChunk lc, int L, int C, int N1, const 
     if (sizeof(T) == 4) {
         const float lam = (float)lc.lam[l];
         const float len = level_len ? level_len[i] : (float)n;
-        const float p = __fmul_rn(lam, len);
-        pen[i] = (T)p;
-        if (level_len && !(p == 0.0f || (p >= 1.8189894e-12f && p <= 1.1805916e21f))) atomicOr(odd, 1u);
+        pen[i] = (T)__fmul_rn(lam, len);
     } else {
         const double len = level_len ? (double)level_len[i] : (double)n;
         pen[i] = (T)__dmul_rn(lc.lam[l], len);
@@ -382,14 +377,6 @@ int launch_quantize(const float *mu, const float *sg, int64_t n_rows, int32_t n_
     const int64_t E = n_rows * (int64_t)n_ch;
     const int64_t n_sub = row_end - row_begin;
     PenT *pen = reinterpret_cast<PenT *>(ws);
-    // the last 64 bytes of the workspace hold the "odd penalties" flag (see k_prepare_penalties)
-    const int Lmax = L < kMaxLambdaChunk ? L : kMaxLambdaChunk;
-    unsigned int *odd = reinterpret_cast<unsigned int *>(reinterpret_cast<char *>(ws) +
-                                                         (size_t)Lmax * n_ch * N1 * sizeof(double) + 192);
-    if (hipMemsetAsync(odd, 0, sizeof(unsigned int), st) != hipSuccess) {
-        set_error("vbq_quantize_f32: hipMemsetAsync failed");
-        return VBQ_ERR_LAUNCH;
-    }
     const bool bc_to_cb = layout == VBQ_LAYOUT_BC_TO_CB && n_ch > 1;
     const bool flat = (n_ch == 1) || (layout == VBQ_LAYOUT_CB) || bc_to_cb;
 
@@ -400,7 +387,7 @@ int launch_quantize(const float *mu, const float *sg, int64_t n_rows, int32_t n_
         const int total = Lc * n_ch * N1;
         const float *len_c = level_len ? level_len + (int64_t)l0 * n_ch * N1 : nullptr;
         hipLaunchKernelGGL((k_prepare_penalties<PenT>), dim3((total + 255) / 256), dim3(256), 0, st, lc, Lc,
-                           (int)n_ch, N1, len_c, pen, odd);
+                           (int)n_ch, N1, len_c, pen);
         VBQ_CHECK_LAUNCH("prepare_penalties");
 
         // element offset of the first processed row: planes / one code book -> row_begin, channel-last -> row_begin * C
@@ -440,7 +427,7 @@ int launch_quantize(const float *mu, const float *sg, int64_t n_rows, int32_t n_
             if constexpr (sizeof(PenT) == 4) {
                 if (fast_ok) {
                     const int r = launch_quant_fast<N>(mu_r, sg_r, n_per_ch, ch_stride, n_ch, table, pen, len_c, Lc, oi, oz, ob,
-                                                       E, vec_ok | (bc_to_cb ? 2 : 0), odd, lc_out, wg_per_cu, st);
+                                                       E, vec_ok | (bc_to_cb ? 2 : 0), lc_out, wg_per_cu, st);
                     if (r != VBQ_OK) return r;
                     continue;
                 }

@@ -155,7 +155,7 @@ __global__ void __launch_bounds__(kFastThreads, VBQ_FAST_WAVES)
 k_quant_fast(const float *__restrict__ mu, const float *__restrict__ sg, long n_per_ch, long ch_stride, int C,
              const float *__restrict__ table, const float *__restrict__ pen, const float *__restrict__ len,
              int L, uint16_t *__restrict__ out_idx, float *__restrict__ out_zhat,
-             float *__restrict__ out_bits, long E, int vec_ok, int dbg, const unsigned int *__restrict__ odd_pen,
+             float *__restrict__ out_bits, long E, int vec_ok, int dbg,
              unsigned long long *__restrict__ level_counts) {
     constexpr int T = table_size(N);
     constexpr int N1 = N + 1;
@@ -164,8 +164,7 @@ k_quant_fast(const float *__restrict__ mu, const float *__restrict__ sg, long n_
     constexpr bool COUNT = MODE == 2;
     // dbg (tests only, VBQ_FAST_DEBUG): 1 = send every solve through the literal scan,
     // 2 = never flag (shows that the flags are what keeps the fast path exact)
-    // *odd_pen != 0: a caller-supplied length table left the range the tie certificate assumes -> literal scan
-    const bool force_slow = dbg == 1 || *odd_pen != 0u, never_flag = dbg == 2;
+    const bool never_flag = dbg == 2;
     constexpr int PS = (N1 + 3) & ~3;                 // penalty row, padded to whole 16-byte LDS reads
     __shared__ float tb[T + 1];
     __shared__ uint32_t scratch[N1 * NE * kFastThreads];
@@ -175,11 +174,17 @@ k_quant_fast(const float *__restrict__ mu, const float *__restrict__ sg, long n_
         for (int i = threadIdx.x; i < N1 * NE * kFastThreads; i += blockDim.x) scratch[i] = 0;
     }
     for (int i = threadIdx.x; i < T; i += blockDim.x) tb[i] = table[(long)c * T + i];
+    // A caller-supplied length table may yield a penalty outside {0} U [2^-39, 2^70], the range the tie certificate below
+    // assumes: the workgroup that stages such a value sends every solve of its own through the literal scan (same answers,
+    // slower) instead of trusting a precondition it cannot see.
+    int odd = 0;
     for (int i = threadIdx.x; i < L * PS; i += blockDim.x) {
         const int l = i / PS, n = i - l * PS;
-        penl[i] = n < N1 ? pen[((long)l * C + c) * N1 + n] : 0.0f;
+        const float p = n < N1 ? pen[((long)l * C + c) * N1 + n] : 0.0f;
+        penl[i] = p;
+        odd |= (len != nullptr && !(p == 0.0f || (p >= 1.8189894e-12f && p <= 1.1805916e21f))) ? 1 : 0;
     }
-    __syncthreads();
+    const bool force_slow = dbg == 1 || __syncthreads_or(odd) != 0;
 
     const long base = (long)c * ch_stride;
     const long nquads = (n_per_ch + NE - 1) / NE;
@@ -700,7 +705,7 @@ k_level_counts_hull(const float *__restrict__ mu, const float *__restrict__ sg, 
 template <int N>
 int launch_quant_fast(const float *mu, const float *sg, int64_t n_per_ch, int64_t ch_stride, int32_t n_ch, const float *table,
                       const float *pen, const float *len, int32_t L, uint16_t *out_idx, float *out_zhat,
-                      float *out_bits, int64_t E, int vec_ok, const unsigned int *odd_pen,
+                      float *out_bits, int64_t E, int vec_ok,
                       unsigned long long *level_counts, int wg_per_cu, hipStream_t st) {
     const int64_t nquads = (n_per_ch + kFastNE - 1) / kFastNE;
     int64_t gx = (nquads + kFastThreads - 1) / kFastThreads;
@@ -727,13 +732,13 @@ int launch_quant_fast(const float *mu, const float *sg, int64_t n_per_ch, int64_
     static const int dbg = [] { const char *e = getenv("VBQ_FAST_DEBUG"); return e ? atoi(e) : 0; }();
     if (level_counts)
         hipLaunchKernelGGL((k_quant_fast<N, 2>), grid, block, 0, st, mu, sg, (long)n_per_ch, (long)ch_stride, (int)n_ch, table,
-                           pen, len, (int)L, out_idx, out_zhat, out_bits, (long)E, vec_ok, dbg, odd_pen, level_counts);
+                           pen, len, (int)L, out_idx, out_zhat, out_bits, (long)E, vec_ok, dbg, level_counts);
     else if (out_zhat || out_bits)
         hipLaunchKernelGGL((k_quant_fast<N, 1>), grid, block, 0, st, mu, sg, (long)n_per_ch, (long)ch_stride, (int)n_ch, table,
-                           pen, len, (int)L, out_idx, out_zhat, out_bits, (long)E, vec_ok, dbg, odd_pen, level_counts);
+                           pen, len, (int)L, out_idx, out_zhat, out_bits, (long)E, vec_ok, dbg, level_counts);
     else
         hipLaunchKernelGGL((k_quant_fast<N, 0>), grid, block, 0, st, mu, sg, (long)n_per_ch, (long)ch_stride, (int)n_ch, table,
-                           pen, len, (int)L, out_idx, out_zhat, out_bits, (long)E, vec_ok, dbg, odd_pen, level_counts);
+                           pen, len, (int)L, out_idx, out_zhat, out_bits, (long)E, vec_ok, dbg, level_counts);
     VBQ_CHECK_LAUNCH("quant_fast");
     return VBQ_OK;
 }
@@ -808,7 +813,7 @@ int launch_level_counts_hull10(const float *mu, const float *sg, int64_t n_per_c
 #define VBQ_INST_FAST(NN)                                                                                              \
     template int launch_quant_fast<NN>(const float *, const float *, int64_t, int64_t, int32_t, const float *,        \
                                        const float *, const float *, int32_t, uint16_t *, float *, float *, int64_t,  \
-                                       int, const unsigned int *, unsigned long long *, int, hipStream_t);
+                                       int, unsigned long long *, int, hipStream_t);
 VBQ_FOR_EACH_N(VBQ_INST_FAST)
 #undef VBQ_INST_FAST
 
