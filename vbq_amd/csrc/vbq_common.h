@@ -50,19 +50,25 @@ __device__ __forceinline__ float neg_half_sq_err(float P, float mu, float sigma)
 #define VBQ_FOR_EACH_N(X) X(12) X(11) X(10) X(9) X(8) X(7) X(6) X(5) X(4)
 #endif
 
+// The lambdas of one launch rounded to f32 (TF casts the Python scalar to the tensor dtype), passed in the kernel arguments:
+// the fast kernels form their penalties fl32(lambda) * len in the prologue instead of reading a table another kernel prepared.
+struct Lambdas32 {
+    float lam[kMaxLambdaChunk];
+};
+
 // vbq_quantize_fast.hip.  Elements of channel c start at c * ch_stride (n_per_ch of them are processed); E is the
 // distance between the lambda planes of the outputs.  level_counts != NULL selects the counting mode (no element
 // output).  wg_per_cu in 1..5 makes the grid persistent at that many workgroups per CU (0: the default sizing).
 template <int N>
 int launch_quant_fast(const float *mu, const float *sg, int64_t n_per_ch, int64_t ch_stride, int32_t n_ch, const float *table,
-                      const float *pen, const float *len, int32_t L, uint16_t *out_idx, float *out_zhat,
+                      const Lambdas32 &lam, const float *len, int32_t L, uint16_t *out_idx, float *out_zhat,
                       float *out_bits, int64_t E, int vec_ok,
                       unsigned long long *level_counts, int wg_per_cu, hipStream_t st);
 
 // K1t (vbq_quantize_fast.hip): first entropy-model pass without a per-lambda loop; N = 10, raw lengths.  Returns 1 when the
 // lambda sweep is not eligible (caller falls back to the dense counting kernel).
 int launch_level_counts_hull10(const float *mu, const float *sg, int64_t n_per_ch, int64_t ch_stride, int32_t n_ch,
-                               const float *table, const float *pen, const double *lam, int32_t L, int vec_ok,
+                               const float *table, const double *lam, int32_t L, int vec_ok,
                                unsigned long long *level_counts, hipStream_t st);
 
 }  // namespace vbq

@@ -386,9 +386,17 @@ int launch_quantize(const float *mu, const float *sg, int64_t n_rows, int32_t n_
         for (int i = 0; i < kMaxLambdaChunk; ++i) lc.lam[i] = i < Lc ? h_lambdas[l0 + i] : 0.0;
         const int total = Lc * n_ch * N1;
         const float *len_c = level_len ? level_len + (int64_t)l0 * n_ch * N1 : nullptr;
-        hipLaunchKernelGGL((k_prepare_penalties<PenT>), dim3((total + 255) / 256), dim3(256), 0, st, lc, Lc,
-                           (int)n_ch, N1, len_c, pen);
-        VBQ_CHECK_LAUNCH("prepare_penalties");
+        bool pen_ready = false;                             // the literal kernels read a prepared table; the fast ones do not
+        auto prepare = [&]() -> int {
+            if (pen_ready) return VBQ_OK;
+            hipLaunchKernelGGL((k_prepare_penalties<PenT>), dim3((total + 255) / 256), dim3(256), 0, st, lc, Lc,
+                               (int)n_ch, N1, len_c, pen);
+            VBQ_CHECK_LAUNCH("prepare_penalties");
+            pen_ready = true;
+            return VBQ_OK;
+        };
+        Lambdas32 l32;
+        for (int i = 0; i < kMaxLambdaChunk; ++i) l32.lam[i] = i < Lc ? (float)lc.lam[i] : 0.0f;
 
         // element offset of the first processed row: planes / one code book -> row_begin, channel-last -> row_begin * C
         const int64_t off = (flat && !bc_to_cb) ? row_begin : row_begin * n_ch;
@@ -418,7 +426,7 @@ int launch_quantize(const float *mu, const float *sg, int64_t n_rows, int32_t n_
             if constexpr (sizeof(PenT) == 4 && N == 10) {
                 // first entropy-model pass (raw lengths, levels only): thresholds instead of a per-lambda loop
                 if (fast_ok && lc_out && !len_c) {
-                    const int r = launch_level_counts_hull10(mu_r, sg_r, n_per_ch, ch_stride, n_ch, table, pen, lc.lam, Lc,
+                    const int r = launch_level_counts_hull10(mu_r, sg_r, n_per_ch, ch_stride, n_ch, table, lc.lam, Lc,
                                                              vec_ok | (bc_to_cb ? 2 : 0), lc_out, st);
                     if (r == VBQ_OK) continue;
                     if (r < 0) return r;
@@ -426,7 +434,7 @@ int launch_quantize(const float *mu, const float *sg, int64_t n_rows, int32_t n_
             }
             if constexpr (sizeof(PenT) == 4) {
                 if (fast_ok) {
-                    const int r = launch_quant_fast<N>(mu_r, sg_r, n_per_ch, ch_stride, n_ch, table, pen, len_c, Lc, oi, oz, ob,
+                    const int r = launch_quant_fast<N>(mu_r, sg_r, n_per_ch, ch_stride, n_ch, table, l32, len_c, Lc, oi, oz, ob,
                                                        E, vec_ok | (bc_to_cb ? 2 : 0), lc_out, wg_per_cu, st);
                     if (r != VBQ_OK) return r;
                     continue;
@@ -442,6 +450,7 @@ int launch_quantize(const float *mu, const float *sg, int64_t n_rows, int32_t n_
                           "lambda in [1.9e-12, 1.8e19]); transpose with vbq_transpose_f32 and use VBQ_LAYOUT_CB instead");
                 return VBQ_ERR_UNSUPPORTED;
             }
+            if (const int r = prepare(); r != VBQ_OK) return r;
             hipLaunchKernelGGL((k_quant_flat<N, PenT>), dim3((unsigned)gx, (unsigned)n_ch), dim3(256), 0, st, mu_r, sg_r,
                                (long)n_per_ch, (long)ch_stride, (int)n_ch, table, pen, len_c, Lc, oi, oz, ob, (long)E, vec_ok);
             VBQ_CHECK_LAUNCH("quant_flat");
@@ -467,6 +476,7 @@ int launch_quantize(const float *mu, const float *sg, int64_t n_rows, int32_t n_
             int64_t gx = (256 + groups - 1) / groups;          // one workgroup per CU
             if (gx > iters) gx = iters;
             if (gx < 1) gx = 1;
+            if (const int r = prepare(); r != VBQ_OK) return r;
             hipLaunchKernelGGL((k_quant_tiled<N, PenT>), dim3((unsigned)gx, (unsigned)groups), dim3(kTiledThreads),
                                lds, st, mu_r, sg_r, (long)n_sub, (int)n_ch, table, pen, len_c, Lc, oi, oz, ob, (long)E);
             VBQ_CHECK_LAUNCH("quant_tiled");

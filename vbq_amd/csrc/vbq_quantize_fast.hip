@@ -153,7 +153,7 @@ __device__ VBQ_SLOW_INLINE uint32_t exact_rank_scan(const float *tb, float z, fl
 template <int N, int MODE>
 __global__ void __launch_bounds__(kFastThreads, VBQ_FAST_WAVES)
 k_quant_fast(const float *__restrict__ mu, const float *__restrict__ sg, long n_per_ch, long ch_stride, int C,
-             const float *__restrict__ table, const float *__restrict__ pen, const float *__restrict__ len,
+             const float *__restrict__ table, Lambdas32 lam, const float *__restrict__ len,
              int L, uint16_t *__restrict__ out_idx, float *__restrict__ out_zhat,
              float *__restrict__ out_bits, long E, int vec_ok, int dbg,
              unsigned long long *__restrict__ level_counts) {
@@ -180,7 +180,8 @@ k_quant_fast(const float *__restrict__ mu, const float *__restrict__ sg, long n_
     int odd = 0;
     for (int i = threadIdx.x; i < L * PS; i += blockDim.x) {
         const int l = i / PS, n = i - l * PS;
-        const float p = n < N1 ? pen[((long)l * C + c) * N1 + n] : 0.0f;
+        // pen[l][n] = fl32(lambda_l) * len[l][c][n], len = n for the raw lengths (quantizer.py:167-175, utils.py:394-396)
+        const float p = n < N1 ? __fmul_rn(lam.lam[l], len ? len[((long)l * C + c) * N1 + n] : (float)n) : 0.0f;
         penl[i] = p;
         odd |= (len != nullptr && !(p == 0.0f || (p >= 1.8189894e-12f && p <= 1.1805916e21f))) ? 1 : 0;
     }
@@ -487,7 +488,7 @@ constexpr float kHullBig = 3.0e38f;
 template <int N>
 __global__ void __launch_bounds__(kFastThreads, VBQ_HULL_WAVES)
 k_level_counts_hull(const float *__restrict__ mu, const float *__restrict__ sg, long n_per_ch, long ch_stride, int C,
-                    const float *__restrict__ table, const float *__restrict__ pen, HullSweep sw, int vec_ok,
+                    const float *__restrict__ table, Lambdas32 lam, HullSweep sw, int vec_ok,
                     unsigned long long *__restrict__ level_counts, int dbg) {
     constexpr int T = table_size(N);
     constexpr int N1 = N + 1;
@@ -507,7 +508,7 @@ k_level_counts_hull(const float *__restrict__ mu, const float *__restrict__ sg, 
     for (int i = threadIdx.x; i < T; i += blockDim.x) tb[i] = table[(long)c * T + i];
     for (int i = threadIdx.x; i < L * PS; i += blockDim.x) {
         const int l = i / PS, n = i - l * PS;
-        penl[i] = n < N1 ? pen[((long)l * C + c) * N1 + n] : 0.0f;
+        penl[i] = n < N1 ? __fmul_rn(lam.lam[l], (float)n) : 0.0f;       // raw lengths, the caller's lambda order
     }
     for (int i = threadIdx.x; i < N * LB * KC; i += blockDim.x) H[i] = 0;
     for (int i = threadIdx.x; i < L * N1; i += blockDim.x) corr[i] = 0;
@@ -704,7 +705,7 @@ k_level_counts_hull(const float *__restrict__ mu, const float *__restrict__ sg, 
 
 template <int N>
 int launch_quant_fast(const float *mu, const float *sg, int64_t n_per_ch, int64_t ch_stride, int32_t n_ch, const float *table,
-                      const float *pen, const float *len, int32_t L, uint16_t *out_idx, float *out_zhat,
+                      const Lambdas32 &lam, const float *len, int32_t L, uint16_t *out_idx, float *out_zhat,
                       float *out_bits, int64_t E, int vec_ok,
                       unsigned long long *level_counts, int wg_per_cu, hipStream_t st) {
     const int64_t nquads = (n_per_ch + kFastNE - 1) / kFastNE;
@@ -732,13 +733,13 @@ int launch_quant_fast(const float *mu, const float *sg, int64_t n_per_ch, int64_
     static const int dbg = [] { const char *e = getenv("VBQ_FAST_DEBUG"); return e ? atoi(e) : 0; }();
     if (level_counts)
         hipLaunchKernelGGL((k_quant_fast<N, 2>), grid, block, 0, st, mu, sg, (long)n_per_ch, (long)ch_stride, (int)n_ch, table,
-                           pen, len, (int)L, out_idx, out_zhat, out_bits, (long)E, vec_ok, dbg, level_counts);
+                           lam, len, (int)L, out_idx, out_zhat, out_bits, (long)E, vec_ok, dbg, level_counts);
     else if (out_zhat || out_bits)
         hipLaunchKernelGGL((k_quant_fast<N, 1>), grid, block, 0, st, mu, sg, (long)n_per_ch, (long)ch_stride, (int)n_ch, table,
-                           pen, len, (int)L, out_idx, out_zhat, out_bits, (long)E, vec_ok, dbg, level_counts);
+                           lam, len, (int)L, out_idx, out_zhat, out_bits, (long)E, vec_ok, dbg, level_counts);
     else
         hipLaunchKernelGGL((k_quant_fast<N, 0>), grid, block, 0, st, mu, sg, (long)n_per_ch, (long)ch_stride, (int)n_ch, table,
-                           pen, len, (int)L, out_idx, out_zhat, out_bits, (long)E, vec_ok, dbg, level_counts);
+                           lam, len, (int)L, out_idx, out_zhat, out_bits, (long)E, vec_ok, dbg, level_counts);
     VBQ_CHECK_LAUNCH("quant_fast");
     return VBQ_OK;
 }
@@ -747,7 +748,7 @@ int launch_quant_fast(const float *mu, const float *sg, int64_t n_per_ch, int64_
 // apart, within 16 octaves), launch.  Returns 1 when the sweep is not eligible (the caller then takes the dense
 // counting kernel), VBQ_OK / an error otherwise.
 int launch_level_counts_hull10(const float *mu, const float *sg, int64_t n_per_ch, int64_t ch_stride, int32_t n_ch,
-                               const float *table, const float *pen, const double *lam, int32_t L, int vec_ok,
+                               const float *table, const double *lam, int32_t L, int vec_ok,
                                unsigned long long *level_counts, hipStream_t st) {
     static const bool off = [] { const char *e = getenv("VBQ_NO_HULL"); return e && e[0] == '1'; }();
     if (off || L < 1 || L > 32) return 1;
@@ -804,15 +805,17 @@ int launch_level_counts_hull10(const float *mu, const float *sg, int64_t n_per_c
         if ((iters + gx - 1) / gx > max_iters) gx = (iters + max_iters - 1) / max_iters;
     }
     static const int dbg = [] { const char *e = getenv("VBQ_FAST_DEBUG"); return e ? atoi(e) : 0; }();
+    Lambdas32 l32;
+    for (int i = 0; i < kMaxLambdaChunk; ++i) l32.lam[i] = i < L ? (float)lam[i] : 0.0f;
     hipLaunchKernelGGL((k_level_counts_hull<10>), dim3((unsigned)gx, (unsigned)n_ch), dim3(kFastThreads), 0, st, mu, sg,
-                       (long)n_per_ch, (long)ch_stride, (int)n_ch, table, pen, sw, vec_ok, level_counts, dbg);
+                       (long)n_per_ch, (long)ch_stride, (int)n_ch, table, l32, sw, vec_ok, level_counts, dbg);
     VBQ_CHECK_LAUNCH("level_counts_hull");
     return VBQ_OK;
 }
 
 #define VBQ_INST_FAST(NN)                                                                                              \
     template int launch_quant_fast<NN>(const float *, const float *, int64_t, int64_t, int32_t, const float *,        \
-                                       const float *, const float *, int32_t, uint16_t *, float *, float *, int64_t,  \
+                                       const Lambdas32 &, const float *, int32_t, uint16_t *, float *, float *, int64_t, \
                                        int, unsigned long long *, int, hipStream_t);
 VBQ_FOR_EACH_N(VBQ_INST_FAST)
 #undef VBQ_INST_FAST
