@@ -252,3 +252,46 @@ def test_histogram_models_assigns_counts_and_lengths(ops, rows, C, L, dt):
     counts2 = torch.full((L, C, T), 7, dtype=dt, device="cuda")
     ops.histogram_models(idx, C, counts2, N=N)                         # counts only
     assert torch.equal(counts2.to(torch.int64), want)
+
+
+def test_integration_md_sequence_through_ctypes_only():
+    """The C-ABI call sequence INTEGRATION.md shows for the whole two-pass build, issued through ctypes alone (no vbq_amd.ops,
+    no pipeline object): the five calls must give the oracle's raw-length models and entropy models bit for bit."""
+    import ctypes as C
+    from vbq_amd import _lib
+    h = _lib.lib()
+    rng = np.random.default_rng(91)
+    B, Cc, L = 2304, 72, 32                                        # 72 x 32 = 2304 rows of bins: the fused K2 flush applies
+    tab_h, mu_h, sg_h = synth(rng, B, Cc)
+    lam = LAM32
+    dev_ = torch.device("cuda")
+    mu = torch.from_numpy(np.ascontiguousarray(mu_h.T)).to(dev_)   # planes [C, B]
+    sg = torch.from_numpy(np.ascontiguousarray(sg_h.T)).to(dev_)
+    table = torch.from_numpy(tab_h).to(dev_)
+    lut1 = -np.log2((np.arange(B + 1, dtype=np.float32) + 1) / np.float32(B + (N + 1)))
+    lut2 = -np.log2((np.arange(B + 1, dtype=np.float32) + 1) / np.float32(B + T))
+    d_lut1, d_lut2 = torch.from_numpy(lut1).to(dev_), torch.from_numpy(lut2).to(dev_)
+    level_counts = torch.zeros((L, Cc, N + 1), dtype=torch.int64, device=dev_)
+    level_len = torch.empty((L, Cc, N + 1), dtype=torch.float32, device=dev_)
+    raw_models = torch.empty_like(level_len)
+    idx = torch.empty((L, Cc, B), dtype=torch.uint16, device=dev_)
+    counts = torch.empty((L, Cc, T), dtype=torch.int64, device=dev_)
+    models = torch.empty((L, Cc, T), dtype=torch.float32, device=dev_)
+    nws = h.vbq_quantize_workspace_bytes(Cc, L, N)
+    ws = torch.empty(nws, dtype=torch.uint8, device=dev_)
+    lamc = (C.c_double * L)(*lam)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert h.vbq_level_counts_f32(p(mu), p(sg), B, Cc, 1, p(table), None, lamc, L, N, p(level_counts), p(ws), nws, st) == 0
+    assert h.vbq_code_lengths_from_counts(p(level_counts), 0, L * Cc * (N + 1), p(d_lut1), B + 1, N + 1, p(level_len), p(raw_models), st) == 0
+    assert h.vbq_quantize_f32(p(mu), p(sg), B, Cc, 1, p(table), p(level_len), lamc, L, N, 0, p(idx), None, None, p(ws), nws, st) == 0
+    assert h.vbq_histogram_models_u16(p(idx), B, Cc, L, N, p(counts), 0, p(d_lut2), B + 1, p(models), st) == 0
+    torch.cuda.synchronize()
+    orc = O.ChannelwiseOracle(Cc, N)
+    orc.build_code_points(lambda xi_: tab_h.T)
+    keys = [np.float32(l) for l in lam]
+    orc.build_entropy_models(mu_h, sg_h, keys, add_n_smoothing=1)
+    for i, k in enumerate(keys):
+        assert np.array_equal(raw_models[i].cpu().numpy(), orc.raw_models[k])
+        assert np.array_equal(models[i].cpu().numpy(), orc.entropy_models[k])
+    assert int(counts.sum().item()) == L * Cc * B
