@@ -13,7 +13,7 @@ namespace vbq {
 namespace {
 
 #ifndef VBQ_HIST_THREADS
-#define VBQ_HIST_THREADS 256
+#define VBQ_HIST_THREADS 512
 #endif
 constexpr int kHistThreads = VBQ_HIST_THREADS;
 #ifndef VBQ_HIST_U
