@@ -450,6 +450,10 @@ k_quant_fast(const float *__restrict__ mu, const float *__restrict__ sg, long n_
 #ifndef VBQ_HULL_NE
 #define VBQ_HULL_NE 2
 #endif
+#ifndef VBQ_HULL_THREADS
+#define VBQ_HULL_THREADS 256
+#endif
+constexpr int kHullThreads = VBQ_HULL_THREADS;
 #ifndef VBQ_HULL_COPIES
 #define VBQ_HULL_COPIES 16
 #endif
@@ -486,7 +490,7 @@ struct HullSweep {
 constexpr float kHullBig = 3.0e38f;
 
 template <int N>
-__global__ void __launch_bounds__(kFastThreads, VBQ_HULL_WAVES)
+__global__ void __launch_bounds__(kHullThreads, (VBQ_HULL_WAVES * 256) / kHullThreads)
 k_level_counts_hull(const float *__restrict__ mu, const float *__restrict__ sg, long n_per_ch, long ch_stride, int C,
                     const float *__restrict__ table, Lambdas32 lam, HullSweep sw, int vec_ok,
                     unsigned long long *__restrict__ level_counts, int dbg) {
@@ -788,9 +792,9 @@ int launch_level_counts_hull10(const float *mu, const float *sg, int64_t n_per_c
         }
     }
     const int64_t nquads = (n_per_ch + VBQ_HULL_NE - 1) / VBQ_HULL_NE;
-    int64_t gx = (nquads + kFastThreads - 1) / kFastThreads;
+    int64_t gx = (nquads + kHullThreads - 1) / kHullThreads;
     static const int rounds = [] { const char *e = getenv("VBQ_HULL_ROUNDS"); return e ? atoi(e) : 1; }();
-    int64_t cap = (int64_t)256 * VBQ_HULL_WAVES * rounds / n_ch;          // VBQ_HULL_WAVES workgroups per CU resident
+    int64_t cap = (int64_t)256 * VBQ_HULL_WAVES * rounds * 256 / kHullThreads / n_ch;    // VBQ_HULL_WAVES x 4 waves per CU resident
     if (cap < 1) cap = 1;
     if (gx > cap) {
         const int64_t iters = gx;
@@ -801,13 +805,13 @@ int launch_level_counts_hull10(const float *mu, const float *sg, int64_t n_per_c
         }
         gx = best;
         // 16-bit partial counters: a half takes at most (32 / copies) lanes x 4 waves x NE per iteration
-        const int64_t max_iters = 65000 / ((32 / VBQ_HULL_COPIES) * 4 * VBQ_HULL_NE);
+        const int64_t max_iters = 65000 / ((32 / VBQ_HULL_COPIES) * (kHullThreads / 64) * VBQ_HULL_NE);
         if ((iters + gx - 1) / gx > max_iters) gx = (iters + max_iters - 1) / max_iters;
     }
     static const int dbg = [] { const char *e = getenv("VBQ_FAST_DEBUG"); return e ? atoi(e) : 0; }();
     Lambdas32 l32;
     for (int i = 0; i < kMaxLambdaChunk; ++i) l32.lam[i] = i < L ? (float)lam[i] : 0.0f;
-    hipLaunchKernelGGL((k_level_counts_hull<10>), dim3((unsigned)gx, (unsigned)n_ch), dim3(kFastThreads), 0, st, mu, sg,
+    hipLaunchKernelGGL((k_level_counts_hull<10>), dim3((unsigned)gx, (unsigned)n_ch), dim3(kHullThreads), 0, st, mu, sg,
                        (long)n_per_ch, (long)ch_stride, (int)n_ch, table, l32, sw, vec_ok, level_counts, dbg);
     VBQ_CHECK_LAUNCH("level_counts_hull");
     return VBQ_OK;
