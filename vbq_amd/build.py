@@ -58,6 +58,10 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
     objdir = os.path.join(LIBDIR, "obj")
     flags_tag = os.path.join(objdir, "flags.txt")
     tag = " ".join(HIPCC_FLAGS + extra)
+    # A tree that arrived with its library but without the object cache (the GPU box: vbq_amd/lib/obj is not shipped) is up
+    # to date when the library is newer than every source: nothing to do, and nothing that needs hipcc.
+    if not force and not extra and not os.path.isdir(objdir) and not _newer(LIB, srcs + headers):
+        return LIB
     os.makedirs(objdir, exist_ok=True)
     if not os.path.exists(flags_tag) or open(flags_tag).read() != tag:
         force = True
