@@ -361,7 +361,7 @@ def run_workload(name, args, torch, dist, dev, rank, world, steps, warmup, detai
     parity["pass2_indices_equal_oracle_on_windows"] = ok
     parity["windows"] = f"{len(starts)} x {win} rows x {C} channels x {L} lambdas"
     # (2) both histograms against a second route on the device, full size: K1 indices (raw lengths) -> K2 -> level sums
-    #     must equal pass 1's K1h counts; K2 of the stored pass-2 indices in one launch must equal the chunked counts
+    #     must equal pass 1's K1t counts; K2 of the stored pass-2 indices in one launch must equal the chunked counts
     from vbq_amd import entropy
     lc = build.level_counts.clone()
     cnt = build.counts.clone()

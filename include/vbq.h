@@ -139,7 +139,8 @@ int vbq_quantize_rows_f32(const float *d_mu, const float *d_sigma, int64_t n_row
                           int32_t workgroups_per_cu, void *stream);
 
 /* ----------------------------------------------------------------------------------
- * K1h  Solve + bit-length histogram in one kernel, nothing written per element.  Replaces the FIRST pass of
+ * K1t / K1h  Solve + bit-length histogram in one kernel, nothing written per element (K1t: raw lengths at N = 10 without a
+ *      per-lambda loop -- ten thresholds per element; K1h: the dense form for everything else).  Replaces the FIRST pass of
  *      ChannelwisePriorCDFQuantizer.build_entropy_models (quantizer.py:96-105): compress_batch_channel_latents
  *      followed by np.bincount(raw_num_bits[:, c], minlength=N+1) per lambda and channel -- which needs the bit
  *      level of every winner and nothing else.  Same arithmetic and tie rules as vbq_quantize_f32 (VBQ_MODE_F32).
@@ -360,7 +361,7 @@ int vbq_unpack_counts_3x21(const int64_t *d_words, int64_t n, int32_t *d_counts,
  *   vbq_comm_unique_id   rank 0 fills VBQ_COMM_ID_BYTES host bytes and hands them to the other ranks by any means
  *   vbq_comm_init        collective: every rank calls it with the same id (the current HIP device is the rank's GPU)
  *   vbq_allreduce_hist   in place on d_counts (int64, or int32 when counts_are_i32 != 0), asynchronous on `stream`;
- *                        works for the level histogram of K1h, the rank histogram of K2 and the packed words of
+ *                        works for the level histogram of K1t / K1h, the rank histogram of K2 and the packed words of
  *                        vbq_pack_counts_3x21 (int64) alike
  *   vbq_comm_destroy
  * RCCL is bound at run time (dlopen): VBQ_ERR_UNSUPPORTED when no librccl.so can be loaded.

@@ -1,5 +1,5 @@
 """The pieces of the two-pass entropy-model build (quantizer.py:82-150) that round 2 added, against the oracle:
-K1h (solve + bit-length histogram, no per-element output), the row-range forms of K1 / K2 that let the host overlap
+K1t / K1h (solve + bit-length histogram, no per-element output), the row-range forms of K1 / K2 that let the host overlap
 them, and the table-driven code lengths.  Counts are integers: everything is compared with array_equal."""
 import numpy as np
 import pytest

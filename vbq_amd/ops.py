@@ -142,7 +142,7 @@ def check_inputs(mu: torch.Tensor, sigma: torch.Tensor):
 def level_counts(mu: torch.Tensor, sigma: torch.Tensor, table_lm: torch.Tensor, lambdas: Sequence[float], *,
                  N: int = 10, level_len: Optional[torch.Tensor] = None, layout="bc", out: Optional[torch.Tensor] = None,
                  workspace: Optional[torch.Tensor] = None):
-    """K1h (vbq_level_counts_f32): the solve of `quantize` followed by the per-(lambda, channel) histogram of the
+    """K1t / K1h (vbq_level_counts_f32; thresholds for raw lengths at N = 10, dense otherwise): the solve of `quantize` followed by the per-(lambda, channel) histogram of the
     winners' bit levels, in one kernel with no per-element output.  Returns int64 [L, C, N+1] (added into `out`)."""
     to_planes = layout in ("bc->cb", LAYOUT_BC_TO_CB)
     layout = LAYOUT_BC if to_planes else _LAYOUTS[layout]

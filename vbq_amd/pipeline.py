@@ -1,7 +1,7 @@
 """The two-pass entropy-model build of ChannelwisePriorCDFQuantizer.build_entropy_models
 (img-compression/quantizer.py:82-150) as ONE stream-ordered device pipeline:
 
-    pass 1   K1h: solve with the current length table -> histogram of bit levels [L, C, N+1]   (quantizer.py:96-105)
+    pass 1   K1t (K1h for sweeps it does not take): solve with raw lengths -> histogram of bit levels [L, C, N+1]   (quantizer.py:96-105)
              (+ all-reduce over ranks)
     lengths  level counts -> -log2 frequencies -> "n + overhead" table [L, C, N+1]              (:105-112, 171-175)
     pass 2   K1 with that table -> rank indices [L, C, B]; K2 -> histogram [L, C, T]            (:119-140)
