@@ -7,6 +7,8 @@
 // win (rounding is monotone, so a farther point of the same level never scores lower), so
 // the same 21-candidate descent as K1 is used, scanned in level-major order.
 #include <stdlib.h>
+#include <string.h>
+#include <math.h>
 
 #include "vbq_common.h"
 
@@ -314,6 +316,394 @@ k_quant_notebook_fast(const float *__restrict__ means, const float *__restrict__
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// K1nt: the beta sweep without a per-beta argmin (N = 10).
+//
+// The notebook's cost of bit level n is a LINE in the penalty weight, err_n + w * n with w = fl32(fl32(2 beta) * fl32(sigma^2))
+// (ipynb:438-440), and the same eleven lines serve every beta of the sweep.  As in K1t (vbq_quantize_fast.hip) the winner is the
+// lower envelope of the lines, described by ten thresholds per element,
+//       T_n = max_{j > n} min_{i <= n} (err_i - err_j) / (j - i),          T_0 >= T_1 >= ... >= T_9,
+// and the level at w is #{ n : w < T_n }.  Here the kernel must produce an INDEX per (element, beta), so the thresholds are
+// turned into positions a_n = #{ l : b_(l) < T_n / sigma^2 } in the SORTED sweep b_(l) = fl32(2 beta_l) (bucket table + one
+// compare, as K1t), the positions into a per-lane column "levels lost at sweep point l" (ten LDS adds), and the sweep is
+// then emitted by walking that column: per solve one 4-bit field, one add and one LDS read of the rank the element has on
+// its current level -- about 3 vector instructions per solve instead of ~50.
+//
+// Exactness.  The reference compares fl64(err_n + w n) (w n is exact) and takes the first minimum in level-major order, i.e.
+// the shallowest level among equal costs and, inside a level, the left neighbour unless the right one is strictly better.
+// Away from every threshold the envelope's margin over any other line is at least |w - T| (integer slopes), so the rounded
+// comparison agrees with the real one when that exceeds 2^-51 of the envelope's height.  Thresholds are computed in f32 from
+// dv_n = f32(err_n) / sigma^2 (every dv_n within 2^-23 of its value, relatively, plus a common factor): a threshold then
+// carries at most 2^-21.4 |T| + 2^-21 dv_n of error (a level j whose dv_j exceeds 2 dv_n only produces negative candidates
+// and cannot raise the maximum above zero), and fl32(b var) is within 2^-24 of b var.  Every threshold therefore gets K1t's
+// guard band |b - T_n / var| <= 2^-20 (dv_n + |T_n / var| (n + 1)); sweep points inside a band are re-solved for that
+// element with the literal scan (exact_rank_scan_nb) and overwritten.  The whole element takes the literal scan when sigma^2
+// or a distortion leaves the range in which those bounds hold, or when on some level the right neighbour beats the left one by
+// less than 2^-45 of err_0, the largest cost a winner can have (fl64(errL + pen) could round onto fl64(errR + pen) and hand
+// the win to the left point).
+// ------------------------------------------------------------------------------------------
+constexpr int kNbKeys = 3072;            // 24 octaves of 128 buckets (the notebook's sweep spans 23.3)
+struct NbSweep {
+    float b[kMaxBetaChunk];              // fl32(2 beta), ascending; +big beyond L
+    unsigned char perm[kMaxBetaChunk];   // position of b[l] in the caller's order
+    int L, key0, nkeys;                  // keys = float bits >> 16; bucket k <-> key0 + k
+    float var_lo, var_hi;                // sigma^2 range in which every fl32(b var) is a normal number
+    unsigned char lut[kNbKeys];          // lut[k] = #{ l : b[l] below the lower edge of bucket k }
+};
+constexpr float kNbBig = 3.0e38f;
+
+__device__ __forceinline__ float nb_min(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float nb_max(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float nb_max3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float nb_min3abs(float a, float b, float c) {
+    float r;
+    asm("v_min3_f32 %0, |%1|, |%2|, |%3|" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+template <bool WITH_VAL, int CW>      // CW: words of eight 4-bit fields per column (positions 0 .. L: 5 for L <= 32, 9 for L <= 64)
+__global__ void __launch_bounds__(256, WITH_VAL ? 2 : 3)
+k_quant_notebook_hull(const float *__restrict__ means, const float *__restrict__ stds, long n,
+                      const double *__restrict__ codebook, NbSweep sw, uint16_t *__restrict__ out_idx,
+                      float *__restrict__ out_val, int vec_ok, int dbg) {
+    constexpr int N = 10, N1 = 11, NE = 2;
+    constexpr int T = table_size(N);
+    // One block of LDS so that the rank table sits at offset 0: the address of rk[r][k][tid] is then (r << 10) | (k * 512 +
+    // tid * 2), which one v_and_or_b32 forms from a 4-bit field.  Slots r = 11 .. 15 of its 16 KB hold the bucket table,
+    // the sweep records and the row numbers.
+    struct Lds {
+        unsigned short rk[N1 * NE * 256];                     // rank of the better side, [N - level][element][thread]
+        unsigned char lut[kNbKeys];                           // (inside rk's 16-slot stride)
+        float4 rec[kMaxBetaChunk + 2];                        // rec[i] = { b[i-1], b[i], b[i+1], - } with -big / +big outside
+        unsigned char perm_s[kMaxBetaChunk];
+        double tb[T + 1];
+        unsigned int cnt[CW * NE * 256];                      // [word][element][thread]: levels lost at sweep point l
+        float vl[WITH_VAL ? N1 * NE * 256 : 1];               // the better side's code point, [N - level][element][thread]
+    };
+    static_assert(sizeof(unsigned short) * N1 * NE * 256 + kNbKeys + 16 * (kMaxBetaChunk + 2) + kMaxBetaChunk <= 16384, "rk stride");
+    __shared__ __align__(16) Lds lds;
+    unsigned short *rk = lds.rk;
+    unsigned char *lut = lds.lut;
+    float4 *rec = lds.rec;
+    unsigned char *perm_s = lds.perm_s;
+    double *tb = lds.tb;
+    unsigned int *cnt = lds.cnt;
+    float *vl = lds.vl;
+    const int L = sw.L;
+    const unsigned int tid = threadIdx.x;
+    for (int i = tid; i < T; i += blockDim.x) tb[i] = codebook[i];
+    for (int k = tid; k < kNbKeys / 4; k += blockDim.x)       // the bucket table travels in the kernel arguments
+        reinterpret_cast<uint32_t *>(lut)[k] = reinterpret_cast<const uint32_t *>(sw.lut)[k];
+    if (tid < kMaxBetaChunk + 2) {
+        const int i = (int)tid;
+        auto at = [&](int l) { return l < 0 ? -kNbBig : (l < L ? sw.b[l < kMaxBetaChunk ? l : kMaxBetaChunk - 1] : kNbBig); };
+        rec[i] = make_float4(at(i - 1), at(i), at(i + 1), 0.0f);
+    }
+    for (int i = tid; i < CW * NE * 256; i += blockDim.x) cnt[i] = 0;
+    if (tid < kMaxBetaChunk) perm_s[tid] = sw.perm[tid];
+    __syncthreads();
+
+    const bool force_slow = dbg == 1, never_flag = dbg == 2;
+    const uint64_t all_l = L >= 64 ? ~0ull : ((1ull << L) - 1ull);
+    const unsigned int lane = tid & 63u;
+    const long npairs = (n + 1) >> 1;
+    for (long q = (long)blockIdx.x * blockDim.x + tid; q < npairs; q += (long)gridDim.x * blockDim.x) {
+        const long i0 = q * 2;
+        const bool full = vec_ok && (i0 + 2 <= n);
+        float m2[NE], s2[NE];
+        if (full) {
+            const float2 mv = *reinterpret_cast<const float2 *>(means + i0);
+            const float2 sv = *reinterpret_cast<const float2 *>(stds + i0);
+            m2[0] = mv.x; m2[1] = mv.y; s2[0] = sv.x; s2[1] = sv.y;
+        } else {
+#pragma unroll
+            for (int k = 0; k < NE; ++k) {
+                const bool ok = i0 + k < n;
+                m2[k] = ok ? means[i0 + k] : 0.0f;
+                s2[k] = ok ? stds[i0 + k] : 1.0f;
+            }
+        }
+        // ---- per level: both neighbours' squared errors as the notebook forms them, the better side's rank (and point)
+        float dv[NE][N1], var[NE], rv[NE];
+        bool slow[NE];
+        {
+            uint32_t g[NE] = {0, 0};
+            uint32_t hi_d0[NE] = {0, 0};
+#pragma unroll
+            for (int k = 0; k < NE; ++k) {
+                var[k] = __fmul_rn(s2[k], s2[k]);
+                rv[k] = __builtin_amdgcn_rcpf(var[k]);
+                slow[k] = !(var[k] >= sw.var_lo && var[k] <= sw.var_hi) || force_slow;
+            }
+#pragma unroll
+            for (int lv = 0; lv <= N; ++lv) {
+#pragma unroll
+                for (int k = 0; k < NE; ++k) {
+                    const double z = (double)m2[k];
+                    const int off = (1 << lv) - 1, m = 1 << lv;
+                    const uint32_t j = g[k];
+                    const double pj = tb[off + j];
+                    const bool below = pj < z;
+                    double du;
+                    uint32_t pos;
+                    double pt = pj;
+                    if (lv == 0) {
+                        du = sq_err(pj, z);
+                        pos = 0;
+                        hi_d0[k] = (uint32_t)__double2hiint(du);
+                    } else {
+                        int jo = below ? (int)j + 1 : (int)j - 1;
+                        jo = jo < 0 ? 0 : (jo > m - 1 ? m - 1 : jo);
+                        const double po = tb[off + jo];
+                        const double ej = sq_err(pj, z), eo = sq_err(po, z);
+                        const double errL = below ? ej : eo, errR = below ? eo : ej;
+                        const bool r_better = errR < errL;
+                        du = r_better ? errR : errL;
+                        pos = (r_better != below) ? j : (uint32_t)jo;      // L is j when below, R is j when not
+                        pt = (r_better != below) ? pj : po;
+                        // a level only wins with a cost <= err_0 (level 0 pays no penalty): if the right side is better by
+                        // less than 2^-45 err_0, fl64(errL + pen) could round onto fl64(errR + pen) and the left point win
+                        const uint32_t hg = (uint32_t)__double2hiint(__dsub_rn(errL, errR)) + (45u << 20);
+                        slow[k] = slow[k] || (r_better && hg <= hi_d0[k] + (1u << 20));
+                    }
+                    g[k] = 2 * j + (below ? 1u : 0u);
+                    dv[k][lv] = __fmul_rn((float)du, rv[k]);
+                    rk[((N - lv) * NE + k) * 256 + tid] = (unsigned short)(((2 * pos + 1) << (N - lv)) - 1);
+                    if (WITH_VAL) vl[((N - lv) * NE + k) * 256 + tid] = (float)pt;
+                }
+            }
+        }
+        // ---- thresholds in units of b = w / sigma^2, positions in the sorted sweep, guard bands, the "levels lost" column
+        uint64_t flags[NE];
+#pragma unroll
+        for (int k = 0; k < NE; ++k) {
+            const bool valid = i0 + k < n;
+            float Pm[N1], Tn[N];
+            uint64_t near[N];
+            float big = dv[k][0];
+#pragma unroll
+            for (int j = 1; j + 1 < N1; j += 2) big = nb_max3(big, dv[k][j], dv[k][j + 1]);
+            uint64_t fl = (!(big < kNbBig) || slow[k]) ? all_l : 0ull;
+            uint64_t any_near = 0;
+#pragma unroll
+            for (int nn = 0; nn < N; ++nn) {
+#pragma unroll
+                for (int j = nn + 1; j < N1; ++j) {
+                    const float r = __fmul_rn(__fsub_rn(dv[k][nn], dv[k][j]), 1.0f / (float)(j - nn));
+                    Pm[j] = nn == 0 ? r : nb_min(Pm[j], r);
+                }
+                float t = Pm[nn + 1];
+                {
+                    int j = nn + 2;
+#pragma unroll
+                    for (; j + 1 < N1; j += 2) t = nb_max3(t, Pm[j], Pm[j + 1]);
+                    if (j < N1) t = nb_max(t, Pm[j]);
+                }
+                t = nb_min(t, 1.0e38f);
+                Tn[nn] = t;
+                const int key = min(max(((int)__float_as_uint(t) >> 16) - sw.key0, 0), sw.nkeys - 1);
+                const uint32_t c0 = lut[key];
+                const float4 nb = rec[c0];
+                const uint32_t a = c0 + (nb.y < t ? 1u : 0u);          // b_(a-1) < T <= b_(a)
+                const float G = __fmul_rn(fmaf(fabsf(t), (float)(nn + 1), dv[k][nn]), 9.5367431640625e-07f);
+                const float dist = nb_min3abs(__fsub_rn(t, nb.x), __fsub_rn(t, nb.y), __fsub_rn(t, nb.z));
+                near[nn] = __builtin_amdgcn_ballot_w64(dist <= G);
+                any_near |= near[nn];
+                atomicAdd(&cnt[((a >> 3) * NE + k) * 256 + tid], 1u << (4u * (a & 7u)));
+            }
+            if (any_near != 0) {                               // rare: list the sweep points inside the band(s)
+#pragma unroll
+                for (int nn = 0; nn < N; ++nn) {
+                    if (near[nn] == 0) continue;
+                    if ((near[nn] >> lane) & 1ull) {
+                        const float G = __fmul_rn(fmaf(fabsf(Tn[nn]), (float)(nn + 1), dv[k][nn]), 9.5367431640625e-07f);
+                        for (int l = 0; l < L; ++l)
+                            fl |= (fabsf(__fsub_rn(sw.b[l], Tn[nn])) <= G) ? (1ull << l) : 0ull;
+                    }
+                }
+            }
+            flags[k] = (valid && !never_flag) ? (fl & all_l) : 0ull;
+        }
+        // ---- emit the sweep: walk the column, level index r = N - level only grows.  The fields of a word sum to at most 10,
+        // so one multiplication by 0x11111111 turns them into their eight running sums (no carries between fields); the
+        // running total of the words before enters as an addend of field 0.
+        uint32_t cw[CW][NE];
+#pragma unroll
+        for (int wd = 0; wd < CW; ++wd)
+            if (wd * 8 <= L) {
+#pragma unroll
+                for (int k = 0; k < NE; ++k) cw[wd][k] = atomicExch(&cnt[(wd * NE + k) * 256 + tid], 0u);    // read and clear
+            }
+        if (full) {
+            const char *rkb = reinterpret_cast<const char *>(rk);
+            const char *vlb = reinterpret_cast<const char *>(vl);
+            uint16_t *oi = out_idx + i0;
+            float *ovp = WITH_VAL ? out_val + i0 : nullptr;
+            uint32_t base[NE], run[NE] = {0, 0};
+#pragma unroll
+            for (int k = 0; k < NE; ++k) base[k] = (k * 256 + tid) * 2;            // bits 0 .. 9; the level index goes into bits 10 .. 13
+            const int nfull = L >> 3;
+#pragma unroll
+            for (int wd = 0; wd < CW - 1; ++wd) {
+                if (wd > nfull) break;
+                const uint2 pw = reinterpret_cast<const uint2 *>(sw.perm)[wd];      // eight row numbers, one scalar load
+                uint32_t P[NE];
+#pragma unroll
+                for (int k = 0; k < NE; ++k) {
+                    P[k] = (cw[wd][k] + run[k]) * 0x11111111u;
+                    run[k] = P[k] >> 28;
+                }
+                auto addr = [&](int j, int k) {
+                    const uint32_t sh = j < 3 ? (P[k] << (10 - 4 * j)) : (P[k] >> (4 * j - 10));
+                    return (sh & 0x3c00u) | base[k];
+                };
+                auto row = [&](int j) { return ((j < 4 ? pw.x : pw.y) >> (8 * (j & 3))) & 0xffu; };
+                if (wd < nfull) {                                                     // a whole word: eight sweep points, no tests
+                    uint32_t rank[8][NE];
+                    float val[8][NE];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+#pragma unroll
+                        for (int k = 0; k < NE; ++k) {
+                            const uint32_t ad = addr(j, k);
+                            rank[j][k] = *reinterpret_cast<const unsigned short *>(rkb + ad);
+                            if (WITH_VAL) val[j][k] = *reinterpret_cast<const float *>(vlb + 2 * ad);
+                        }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        *reinterpret_cast<uint32_t *>(oi + (long)row(j) * n) = rank[j][0] | (rank[j][1] << 16);
+                        if (WITH_VAL) *reinterpret_cast<float2 *>(ovp + (long)row(j) * n) = make_float2(val[j][0], val[j][1]);
+                    }
+                } else {
+                    const int lim = L - wd * 8;
+#pragma unroll
+                    for (int j = 0; j < 7; ++j) {
+                        if (j >= lim) break;
+                        const uint32_t a0 = addr(j, 0), a1 = addr(j, 1);
+                        *reinterpret_cast<uint32_t *>(oi + (long)row(j) * n) =
+                            *reinterpret_cast<const unsigned short *>(rkb + a0) | ((uint32_t)*reinterpret_cast<const unsigned short *>(rkb + a1) << 16);
+                        if (WITH_VAL)
+                            *reinterpret_cast<float2 *>(ovp + (long)row(j) * n) =
+                                make_float2(*reinterpret_cast<const float *>(vlb + 2 * a0), *reinterpret_cast<const float *>(vlb + 2 * a1));
+                    }
+                }
+            }
+        } else {
+            uint32_t r[NE] = {0, 0};
+            for (int l = 0; l < L; ++l) {
+#pragma unroll
+                for (int k = 0; k < NE; ++k) {
+                    uint32_t w = 0;
+#pragma unroll
+                    for (int wd = 0; wd < CW - 1; ++wd) w = (l >> 3) == wd ? cw[wd][k] : w;
+                    r[k] += (w >> (4 * (l & 7))) & 15u;
+                    if (i0 + k < n) {
+                        const long o = (long)sw.perm[l] * n + i0 + k;
+                        out_idx[o] = rk[(r[k] * NE + k) * 256 + tid];
+                        if (WITH_VAL) out_val[o] = vl[(r[k] * NE + k) * 256 + tid];
+                    }
+                }
+            }
+        }
+        // ---- sweep points inside a guard band: literal scan, result overwrites the emitted one
+        if (__builtin_amdgcn_ballot_w64((flags[0] | flags[1]) != 0ull) != 0ull) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the emitted values have landed before they are replaced
+#pragma unroll
+            for (int k = 0; k < NE; ++k) {
+                while (__builtin_amdgcn_ballot_w64(flags[k] != 0ull) != 0ull) {
+                    if (flags[k] != 0ull) {
+                        const int l = __builtin_ctzll(flags[k]);
+                        flags[k] &= flags[k] - 1ull;
+                        const float bl = rec[l].y;
+                        const uint32_t rank = exact_rank_scan_nb<N>(tb, (double)m2[k], (double)__fmul_rn(bl, var[k]));
+                        const long o = (long)perm_s[l] * n + i0 + k;
+                        out_idx[o] = (uint16_t)rank;
+                        if (WITH_VAL) {
+                            const uint32_t kk = rank + 1;
+                            const int tz = __builtin_ctz(kk);
+                            out_val[o] = (float)tb[(1 << (N - tz)) - 1 + (kk >> (tz + 1))];
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// Host side of K1nt: sort the sweep by fl32(2 beta), check that the bucket table applies (distinct values at least one
+// bucket apart, within 24 octaves).  Returns 1 when the sweep is not eligible (the caller takes the per-beta kernel).
+int launch_notebook_hull10(const float *means, const float *stds, int64_t n, const double *codebook, const double *betas,
+                           int Lc, uint16_t *oi, float *ov, int vec_ok, int dbg, hipStream_t st) {
+    static const bool off = [] { const char *e = getenv("VBQ_NO_HULL"); return e && e[0] == '1'; }();
+    if (off || Lc < 1 || Lc > kMaxBetaChunk) return 1;
+    NbSweep sw;
+    int order[kMaxBetaChunk];
+    float b[kMaxBetaChunk];
+    for (int i = 0; i < Lc; ++i) { order[i] = i; b[i] = (float)(2.0 * betas[i]); }
+    for (int i = 1; i < Lc; ++i)
+        for (int j = i; j > 0 && b[order[j]] < b[order[j - 1]]; --j) { const int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t; }
+    int prev_key = -1;
+    for (int i = 0; i < kMaxBetaChunk; ++i) { sw.b[i] = kNbBig; sw.perm[i] = 0; }
+    for (int i = 0; i < Lc; ++i) {
+        const float v = b[order[i]];
+        if (!(v >= 2e-12f && v <= 2e18f)) return 1;
+        uint32_t bits;
+        memcpy(&bits, &v, 4);
+        const int key = (int)(bits >> 16);
+        if (key <= prev_key) return 1;
+        prev_key = key;
+        sw.b[i] = v;
+        sw.perm[i] = (unsigned char)order[i];
+    }
+    uint32_t b0;
+    memcpy(&b0, &sw.b[0], 4);
+    sw.key0 = (int)(b0 >> 16);
+    sw.nkeys = prev_key - sw.key0 + 2;
+    sw.L = Lc;
+    if (sw.nkeys > kNbKeys) return 1;
+    {
+        int l = 0;
+        for (int k = 0; k < kNbKeys; ++k) {
+            while (l < Lc) {
+                uint32_t bits;
+                memcpy(&bits, &sw.b[l], 4);
+                if ((int)(bits >> 16) < sw.key0 + k) ++l; else break;
+            }
+            sw.lut[k] = (unsigned char)l;
+        }
+    }
+    sw.var_lo = fmaxf(4e-38f / sw.b[0], 1e-30f);
+    sw.var_hi = fminf(1e38f / sw.b[Lc - 1], 1e30f);
+    int64_t gx = ((n + 1) / 2 + 255) / 256;
+    const int64_t cap = 256 * (ov ? 2 : 3) * 2;              // persistent grid: every CU's resident workgroups, two rounds
+    if (gx > cap) gx = cap;
+    if (gx < 1) gx = 1;
+#define VBQ_NB_HULL(V, W)                                                                                             \
+    hipLaunchKernelGGL((k_quant_notebook_hull<V, W>), dim3((unsigned)gx), dim3(256), 0, st, means, stds, (long)n, codebook, sw, oi, \
+                       ov, vec_ok, dbg)
+    if (ov) {
+        if (Lc <= 32) VBQ_NB_HULL(true, 5); else VBQ_NB_HULL(true, 9);
+    } else {
+        if (Lc <= 32) VBQ_NB_HULL(false, 5); else VBQ_NB_HULL(false, 9);
+    }
+#undef VBQ_NB_HULL
+    VBQ_CHECK_LAUNCH("quant_notebook_hull");
+    return VBQ_OK;
+}
+
 template <int N>
 int launch_notebook(const float *means, const float *stds, int64_t n, const double *codebook,
                     const double *h_betas, int32_t nb, uint16_t *out_idx, float *out_val, hipStream_t st) {
@@ -333,6 +723,10 @@ int launch_notebook(const float *means, const float *stds, int64_t n, const doub
         static const int dbg = [] { const char *e = getenv("VBQ_FAST_DEBUG"); return e ? atoi(e) : 0; }();
         bool fast_ok = !plain;                      // the tie certificate wants betas in a sane range
         for (int i = 0; i < Lc; ++i) fast_ok = fast_ok && (bc.beta[i] >= 1e-12 && bc.beta[i] <= 1e18);
+        if (fast_ok && N == 10 && Lc >= 6) {           // below that the thresholds cost more than the solves they replace
+            const int rc = launch_notebook_hull10(means, stds, n, codebook, bc.beta, Lc, oi, ov, vec_ok, dbg, st);
+            if (rc != 1) { if (rc != VBQ_OK) return rc; continue; }
+        }
         if (fast_ok)
             hipLaunchKernelGGL((k_quant_notebook_fast<N>), dim3((unsigned)gx), dim3(256), 0, st, means, stds, (long)n,
                                codebook, bc, Lc, oi, ov, vec_ok, dbg);
