@@ -557,7 +557,7 @@ def run_notebook(args, torch, dev, workload=None, steps=None, warmup=None, cpu=T
            "config": {"workload": f"{name}: {desc}; {L}-point beta sweep exp(linspace(log 0.01, log 1e5, {L})), notebook arithmetic "
                                   f"(K1n, f64 squared error, ipynb:429-443) + K2 histogram (empirical_entropy, ipynb:452-455); "
                                   f"one solve per (element, beta) per step", "elements_per_gpu": rows, "lambdas": L},
-           "roofline": {"bound": "hbm", "kernel": "k_quant_notebook_fast", "achieved": alg / (k1_ms * 1e-3) / 1e9,
+           "roofline": {"bound": "hbm", "kernel": "k_quant_notebook_hull", "achieved": alg / (k1_ms * 1e-3) / 1e9,
                         "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": alg / (k1_ms * 1e-3) / HBM_PEAK, "traffic": None,
                         "algorithmic_bytes_per_launch": alg, "avg_launch_ms": k1_ms}}
     # the notebook's own brute force over all 2047 code points (C oracle, OpenMP), a bounded sample

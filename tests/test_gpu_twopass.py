@@ -295,3 +295,76 @@ def test_integration_md_sequence_through_ctypes_only():
         assert np.array_equal(raw_models[i].cpu().numpy(), orc.raw_models[k])
         assert np.array_equal(models[i].cpu().numpy(), orc.entropy_models[k])
     assert int(counts.sum().item()) == L * Cc * B
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# K1nt: the notebook's beta sweep (ipynb:429-443, cell 32) from per-element thresholds -- indices and values
+# ---------------------------------------------------------------------------------------------------------------------
+def _notebook_case(rng, n):
+    scale = np.float32(np.exp(rng.uniform(np.log(0.2), np.log(5.0))))
+    pts, lens = O.notebook_code_book(scale, N)
+    srt = np.sort(pts)
+    mids = (0.5 * (srt[:-1] + srt[1:])).astype(np.float32)
+    means = np.concatenate([srt.astype(np.float32), mids, np.float32([srt[0] - 40 * scale, srt[-1] + 40 * scale, 0.0]),
+                            (scale * rng.standard_t(4, n)).astype(np.float32)]).astype(np.float32)
+    stds = (np.exp(rng.normal(-2, 1.5, means.size)) * scale).astype(np.float32)
+    stds[::7] = np.float32(0.99999994) * scale
+    stds[3::101] = np.float32(1e-6) * scale                  # err / sigma^2 beyond every threshold of the sweep
+    stds[5::103] = np.float32(1e4) * scale
+    return pts, lens, means, stds
+
+
+def _check_notebook(ops, means, stds, pts, lens, betas, want_values=True):
+    idx, val = ops.quantize_notebook(dev(means), dev(stds), dev(pts), betas, N=N, want_values=want_values)
+    idx = idx.cpu().numpy().astype(np.int64)
+    r2s = O.level_major_to_rank(N)
+    for i, b in enumerate(betas):
+        v, slot = CO.compress_coordinates(means, stds, b, pts, lens, threads=8)
+        assert np.array_equal(idx[i], r2s[slot]), (len(betas), i, b)
+        if want_values:
+            assert np.array_equal(val[i].cpu().numpy(), v), (len(betas), i, b)
+
+
+def test_notebook_threshold_kernel_sweeps(ops):
+    """K1nt on exact code-point hits, mid-points, inputs outside the code book and extreme sigmas, for the sweeps it takes
+    (6 to 64 betas, any order: the notebook's 50, 32, 64, reversed, a random subset) and the ones it hands to the per-beta
+    kernel (fewer than 6 betas, repeated values, two betas in one bucket, more than 24 octaves, out-of-range betas); odd and
+    even lengths (packed and unpacked stores); with and without the quantised values."""
+    rng = np.random.default_rng(77)
+    pts, lens, means, stds = _notebook_case(rng, 9000)
+    nb50 = [float(b) for b in np.exp(np.linspace(np.log(0.01), np.log(1e5), 50))]        # ipynb cell 32
+    sweeps = [nb50, nb50[::-1], [float(b) for b in np.exp(np.linspace(np.log(0.01), np.log(1e5), 32))],
+              [float(b) for b in np.exp(np.linspace(np.log(0.003), np.log(3e3), 64))],
+              [nb50[i] for i in rng.permutation(50)[:9]], nb50[:6], [2.0 ** k for k in range(-9, 12)],
+              nb50[:5],                                              # too short           -> per-beta kernel
+              [1.0, 1.0, 2.0, 3.0, 5.0, 9.0, 17.0],                  # repeated value      -> per-beta kernel
+              [1.0, 1.0 + 2.0 ** -9, 2.0, 4.0, 8.0, 16.0],           # same bucket         -> per-beta kernel
+              [1e-7, 1e-3, 1.0, 1e3, 1e6, 1e9, 1e12]]                # > 24 octaves        -> per-beta kernel
+    for betas in sweeps:
+        _check_notebook(ops, means, stds, pts, lens, betas)
+    _check_notebook(ops, means[:-1], stds[:-1], pts, lens, nb50)                 # odd length
+    _check_notebook(ops, means[1:], stds[1:], pts, lens, nb50[:32])              # odd length, base not 8-byte aligned
+    _check_notebook(ops, means, stds, pts, lens, nb50, want_values=False)
+
+
+@pytest.mark.timeout(900)
+def test_notebook_threshold_kernel_guard_machinery():
+    """tools/stress_notebook.py, whose last round puts betas exactly on level-change thresholds of chosen elements:
+    (0) as built and (1) with every (element, beta) forced through the literal scan the indices and values equal the
+    2047-point brute force; (2) with the guard bands switched off mismatches appear on the same data."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "tools", "stress_notebook.py"), "120000", "4"]
+
+    def run(dbg):
+        env = dict(os.environ, VBQ_FAST_DEBUG=str(dbg))
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=800)
+        return r.returncode, r.stdout + r.stderr[-2000:]
+    rc0, out0 = run(0)
+    assert rc0 == 0, out0
+    rc1, out1 = run(1)
+    assert rc1 == 0, out1
+    rc2, out2 = run(2)
+    assert rc2 == 1, out2

@@ -343,11 +343,12 @@ k_quant_notebook_fast(const float *__restrict__ means, const float *__restrict__
 // less than 2^-45 of err_0, the largest cost a winner can have (fl64(errL + pen) could round onto fl64(errR + pen) and hand
 // the win to the left point).
 // ------------------------------------------------------------------------------------------
-constexpr int kNbKeys = 3072;            // 24 octaves of 128 buckets (the notebook's sweep spans 23.3)
+constexpr int kNbKeys = 1536;            // 24 octaves of 64 buckets (the notebook's sweep spans 23.3)
+constexpr int kNbKeyShift = 17;          // key = float bits >> 17: sign, exponent, 6 mantissa bits
 struct NbSweep {
     float b[kMaxBetaChunk];              // fl32(2 beta), ascending; +big beyond L
     unsigned char perm[kMaxBetaChunk];   // position of b[l] in the caller's order
-    int L, key0, nkeys;                  // keys = float bits >> 16; bucket k <-> key0 + k
+    int L, key0, nkeys;                  // keys = float bits >> kNbKeyShift; bucket k <-> key0 + k
     float var_lo, var_hi;                // sigma^2 range in which every fl32(b var) is a normal number
     unsigned char lut[kNbKeys];          // lut[k] = #{ l : b[l] below the lower edge of bucket k }
 };
@@ -375,7 +376,7 @@ __device__ __forceinline__ float nb_min3abs(float a, float b, float c) {
 }
 
 template <bool WITH_VAL, int CW>      // CW: words of eight 4-bit fields per column (positions 0 .. L: 5 for L <= 32, 9 for L <= 64)
-__global__ void __launch_bounds__(256, WITH_VAL ? 2 : 3)
+__global__ void __launch_bounds__(256, WITH_VAL ? 2 : (CW <= 5 ? 4 : 3))
 k_quant_notebook_hull(const float *__restrict__ means, const float *__restrict__ stds, long n,
                       const double *__restrict__ codebook, NbSweep sw, uint16_t *__restrict__ out_idx,
                       float *__restrict__ out_val, int vec_ok, int dbg) {
@@ -512,17 +513,32 @@ k_quant_notebook_hull(const float *__restrict__ means, const float *__restrict__
                     for (; j + 1 < N1; j += 2) t = nb_max3(t, Pm[j], Pm[j + 1]);
                     if (j < N1) t = nb_max(t, Pm[j]);
                 }
-                t = nb_min(t, 1.0e38f);
-                Tn[nn] = t;
-                const int key = min(max(((int)__float_as_uint(t) >> 16) - sw.key0, 0), sw.nkeys - 1);
-                const uint32_t c0 = lut[key];
-                const float4 nb = rec[c0];
-                const uint32_t a = c0 + (nb.y < t ? 1u : 0u);          // b_(a-1) < T <= b_(a)
-                const float G = __fmul_rn(fmaf(fabsf(t), (float)(nn + 1), dv[k][nn]), 9.5367431640625e-07f);
-                const float dist = nb_min3abs(__fsub_rn(t, nb.x), __fsub_rn(t, nb.y), __fsub_rn(t, nb.z));
-                near[nn] = __builtin_amdgcn_ballot_w64(dist <= G);
-                any_near |= near[nn];
-                atomicAdd(&cnt[((a >> 3) * NE + k) * 256 + tid], 1u << (4u * (a & 7u)));
+                Tn[nn] = nb_min(t, 1.0e38f);
+            }
+            // positions: bucket -> count of sweep points below the bucket -> the one sweep point that may share it.  The ten
+            // table reads go out together, then the ten record reads (two LDS latencies per element instead of twenty).
+            uint32_t c0[N];
+#pragma unroll
+            for (int nn = 0; nn < N; ++nn) {
+                const int key = min(max(((int)__float_as_uint(Tn[nn]) >> kNbKeyShift) - sw.key0, 0), sw.nkeys - 1);
+                c0[nn] = lut[key];
+            }
+#pragma unroll
+            for (int h = 0; h < N; h += 5) {
+                float4 nb[5];
+#pragma unroll
+                for (int i = 0; i < 5; ++i) nb[i] = rec[c0[h + i]];
+#pragma unroll
+                for (int i = 0; i < 5; ++i) {
+                    const int nn = h + i;
+                    const float t = Tn[nn];
+                    const uint32_t a = c0[nn] + (nb[i].y < t ? 1u : 0u);          // b_(a-1) < T <= b_(a)
+                    const float G = __fmul_rn(fmaf(fabsf(t), (float)(nn + 1), dv[k][nn]), 9.5367431640625e-07f);
+                    const float dist = nb_min3abs(__fsub_rn(t, nb[i].x), __fsub_rn(t, nb[i].y), __fsub_rn(t, nb[i].z));
+                    near[nn] = __builtin_amdgcn_ballot_w64(dist <= G);
+                    any_near |= near[nn];
+                    atomicAdd(&cnt[((a >> 3) * NE + k) * 256 + tid], 1u << (4u * (a & 7u)));
+                }
             }
             if (any_near != 0) {                               // rare: list the sweep points inside the band(s)
 #pragma unroll
@@ -662,7 +678,7 @@ int launch_notebook_hull10(const float *means, const float *stds, int64_t n, con
         if (!(v >= 2e-12f && v <= 2e18f)) return 1;
         uint32_t bits;
         memcpy(&bits, &v, 4);
-        const int key = (int)(bits >> 16);
+        const int key = (int)(bits >> kNbKeyShift);
         if (key <= prev_key) return 1;
         prev_key = key;
         sw.b[i] = v;
@@ -670,7 +686,7 @@ int launch_notebook_hull10(const float *means, const float *stds, int64_t n, con
     }
     uint32_t b0;
     memcpy(&b0, &sw.b[0], 4);
-    sw.key0 = (int)(b0 >> 16);
+    sw.key0 = (int)(b0 >> kNbKeyShift);
     sw.nkeys = prev_key - sw.key0 + 2;
     sw.L = Lc;
     if (sw.nkeys > kNbKeys) return 1;
@@ -680,7 +696,7 @@ int launch_notebook_hull10(const float *means, const float *stds, int64_t n, con
             while (l < Lc) {
                 uint32_t bits;
                 memcpy(&bits, &sw.b[l], 4);
-                if ((int)(bits >> 16) < sw.key0 + k) ++l; else break;
+                if ((int)(bits >> kNbKeyShift) < sw.key0 + k) ++l; else break;
             }
             sw.lut[k] = (unsigned char)l;
         }
@@ -688,7 +704,8 @@ int launch_notebook_hull10(const float *means, const float *stds, int64_t n, con
     sw.var_lo = fmaxf(4e-38f / sw.b[0], 1e-30f);
     sw.var_hi = fminf(1e38f / sw.b[Lc - 1], 1e30f);
     int64_t gx = ((n + 1) / 2 + 255) / 256;
-    const int64_t cap = 256 * (ov ? 2 : 3) * 2;              // persistent grid: every CU's resident workgroups, two rounds
+    static const int rounds = [] { const char *e = getenv("VBQ_HULL_ROUNDS"); return e ? atoi(e) : 2; }();
+    const int64_t cap = 256 * (ov ? 2 : (Lc <= 32 ? 4 : 3)) * rounds;              // persistent grid: every CU's resident workgroups, two rounds
     if (gx > cap) gx = cap;
     if (gx < 1) gx = 1;
 #define VBQ_NB_HULL(V, W)                                                                                             \
