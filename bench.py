@@ -437,7 +437,7 @@ def main():
     args.level_group = dist.new_group() if world > 1 else None
 
     if args.notebook:
-        out = run_notebook(args, torch, dev)
+        out = run_notebook(args, torch, dev, cpu=not args.no_cpu_baseline)
         print(json.dumps(out))
         return
 
@@ -555,7 +555,7 @@ def run_notebook(args, torch, dev, workload=None, steps=None, warmup=None, cpu=T
            "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3, "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
            "config": {"workload": f"{name}: {desc}; {L}-point beta sweep exp(linspace(log 0.01, log 1e5, {L})), notebook arithmetic "
-                                  f"(K1n, f64 squared error, ipynb:429-443) + K2 histogram (empirical_entropy, ipynb:452-455); "
+                                  f"(K1nt, f64 squared error, ipynb:429-443) + K2 histogram (empirical_entropy, ipynb:452-455); "
                                   f"one solve per (element, beta) per step", "elements_per_gpu": rows, "lambdas": L},
            "roofline": {"bound": "hbm", "kernel": "k_quant_notebook_hull", "achieved": alg / (k1_ms * 1e-3) / 1e9,
                         "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": alg / (k1_ms * 1e-3) / HBM_PEAK, "traffic": None,

@@ -5,12 +5,14 @@
 #   SQ counters         two --pmc passes of 8 SQ counters (+ GRBM_GUI_ACTIVE)
 # Counter passes carry --kernel-trace only (gpurun refuses --pmc together with the sys / hip / hsa trace domains).
 #   bash tools/profile_round.sh r2     (run on the GPU box; then python tools/summarize_profile.py r2 here)
+#   bash tools/profile_round.sh r2nb --notebook      the same for the notebook-arithmetic workload (K1nt + K2)
 TAG=${1:-r2}
+EXTRA=${2:-}
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out
-BENCH="python3 bench.py --no-cpu-baseline --no-other-workloads --no-graph --steps 9 --warmup 3"
+BENCH="python3 bench.py $EXTRA --no-cpu-baseline --no-other-workloads --no-graph --steps 9 --warmup 3"
 mkdir -p $OUT
-python3 bench.py --no-other-workloads --steps 20 --warmup 5 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
+python3 bench.py $EXTRA --no-other-workloads --steps 20 --warmup 5 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/${TAG}_stats -o ${TAG} -- $BENCH > $OUT/${TAG}_stats.log 2>&1
 rocprofv3 --output-format csv --kernel-trace --pmc FETCH_SIZE -d $OUT/${TAG}_fetch -o ${TAG} -- $BENCH > $OUT/${TAG}_fetch.log 2>&1
 rocprofv3 --output-format csv --kernel-trace --pmc WRITE_SIZE -d $OUT/${TAG}_write -o ${TAG} -- $BENCH > $OUT/${TAG}_write.log 2>&1
