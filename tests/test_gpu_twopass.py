@@ -356,7 +356,7 @@ def test_notebook_threshold_kernel_guard_machinery():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    cmd = [sys.executable, os.path.join(root, "tools", "stress_notebook.py"), "120000", "4"]
+    cmd = [sys.executable, os.path.join(root, "tools", "stress_notebook.py"), "120000", "5"]
 
     def run(dbg):
         env = dict(os.environ, VBQ_FAST_DEBUG=str(dbg))

@@ -2,7 +2,7 @@
 2047-point brute force (C oracle of compress_coordinates, ipynb:429-443).
     python tools/stress_notebook.py [n] [rounds]
 Rounds cycle through: a short sweep, the notebook's 50 betas, an unsorted sweep with repeats across a launch-chunk boundary
-(dense kernel), and an ADVERSARIAL sweep whose betas put the penalty weight of chosen elements exactly on their own
+(dense kernel), a randomly spaced unsorted sweep of 6 to 64 betas, and an ADVERSARIAL sweep whose betas put the penalty weight of chosen elements exactly on their own
 level-change thresholds (T_n = max_j min_i (err_i - err_j) / (j - i), computed here in float64) -- the case K1nt's guard bands
 exist for.  With VBQ_FAST_DEBUG=2 (bands off) that round must produce mismatches; with 0 and 1 none."""
 import os, sys
@@ -47,7 +47,7 @@ def main():
     dev = torch.device("cuda")
     tot = bad = 0
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 300000
-    for rnd in range(int(sys.argv[2]) if len(sys.argv) > 2 else 4):
+    for rnd in range(int(sys.argv[2]) if len(sys.argv) > 2 else 5):
         scale = float(np.exp(rng.uniform(np.log(0.05), np.log(20))))
         means = (scale * rng.standard_t(4, n)).astype(np.float32)
         stds = (np.exp(rng.normal(-2, 1.5, n)) * scale).astype(np.float32)
@@ -57,9 +57,11 @@ def main():
         means[:k] = srt[rng.integers(0, 2047, k)].astype(np.float32)
         j = rng.integers(0, 2046, k)
         means[k:2 * k] = (0.5 * (srt[j] + srt[j + 1])).astype(np.float32)
-        kind = rnd % 4
+        kind = rnd % 5
         if kind == 3:
             betas = threshold_betas(means, stds, pts, lens, rng, 48)
+        elif kind == 4:                                    # random length, spacing and order
+            betas = [float(b) for b in np.exp(rng.uniform(np.log(1e-4), np.log(1e7), int(rng.integers(6, 65))))]
         else:
             nbeta = [10, 50, 33][kind]
             betas = list(np.exp(np.linspace(np.log(0.01), np.log(1e5), nbeta)))
