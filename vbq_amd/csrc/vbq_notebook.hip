@@ -382,19 +382,17 @@ k_quant_notebook_hull(const float *__restrict__ means, const float *__restrict__
                       float *__restrict__ out_val, int vec_ok, int dbg) {
     constexpr int N = 10, N1 = 11, NE = 2;
     constexpr int T = table_size(N);
-    // One block of LDS so that the rank table sits at offset 0: the address of rk[r][k][tid] is then (r << 10) | (k * 512 +
-    // tid * 2), which one v_and_or_b32 forms from a 4-bit field.  Slots r = 11 .. 15 of its 16 KB hold the bucket table,
-    // the sweep records and the row numbers.
+    // One LDS block.  The byte offset of rk[r][k][tid] inside the rank table is (r << 10) | (k * 512 + tid * 2): the lane part
+    // stays below 1024, so one v_and_or_b32 forms the address from a shifted 4-bit field (emission below).
     struct Lds {
         unsigned short rk[N1 * NE * 256];                     // rank of the better side, [N - level][element][thread]
-        unsigned char lut[kNbKeys];                           // (inside rk's 16-slot stride)
+        unsigned char lut[kNbKeys];
         float4 rec[kMaxBetaChunk + 2];                        // rec[i] = { b[i-1], b[i], b[i+1], - } with -big / +big outside
         unsigned char perm_s[kMaxBetaChunk];
         double tb[T + 1];
         unsigned int cnt[CW * NE * 256];                      // [word][element][thread]: levels lost at sweep point l
         float vl[WITH_VAL ? N1 * NE * 256 : 1];               // the better side's code point, [N - level][element][thread]
     };
-    static_assert(sizeof(unsigned short) * N1 * NE * 256 + kNbKeys + 16 * (kMaxBetaChunk + 2) + kMaxBetaChunk <= 16384, "rk stride");
     __shared__ __align__(16) Lds lds;
     unsigned short *rk = lds.rk;
     unsigned char *lut = lds.lut;
