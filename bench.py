@@ -507,12 +507,46 @@ def main():
             nb = run_notebook(args, torch, dev, workload="embeddings_1e7", steps=5, warmup=2, cpu=False)
             others["embeddings_1e7_notebook"] = {k: nb[k] for k in ("ms_per_step", "value", "unit", "roofline", "parity_vs_oracle_on_sample")}
             others["embeddings_1e7_notebook"]["workload"] = nb["config"]["workload"]
+            others["kodak24_c256_quantize_sweep_raw"] = run_raw_sweep(torch, dev)
         if rank == 0:
             out["workloads"] = others
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def run_raw_sweep(torch, dev, steps=10, warmup=3):
+    """The literal north-star call, quantize(mu, sigma, lmbda) for the 32-point sweep with the reference's raw code lengths
+    (quantizer.py:167-169): ONE pass, indices out, no histogram -- K1e (thresholds + a walk down the staircase)."""
+    from vbq_amd import ops
+    from oracle import c_oracle as CO
+    rows, C, desc = WORKLOADS["kodak24_c256"]
+    mu_h, sg_h, tab_h = make_inputs(rows, C, seed=1000)
+    mu = torch.from_numpy(np.ascontiguousarray(mu_h.T)).to(dev)
+    sg = torch.from_numpy(np.ascontiguousarray(sg_h.T)).to(dev)
+    tab = torch.from_numpy(tab_h).to(dev)
+    L = len(LAMBDAS)
+    idx = torch.empty((L, C, rows), dtype=torch.uint16, device=dev)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    for _ in range(warmup):
+        ops.quantize(mu, sg, tab, LAMBDAS, N=N_BITS, layout="cb", out_idx=idx)
+    for a, b in ev:
+        a.record()
+        ops.quantize(mu, sg, tab, LAMBDAS, N=N_BITS, layout="cb", out_idx=idx)
+        b.record()
+    torch.cuda.synchronize()
+    ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    alg = rows * C * (8 + 2 * L)
+    n = 2048                                                   # parity: the first rows of every channel against the C oracle
+    want = CO.quantize(mu_h[:n], sg_h[:n], tab_h, LAMBDAS, N=N_BITS, threads=CO.max_threads())       # [L, n, C]
+    ok = bool(np.array_equal(idx[:, :, :n].cpu().numpy().transpose(0, 2, 1), want))
+    return {"ms_per_step": ms, "value": rows * C * L / (ms * 1e-3), "unit": "latents/s",
+            "roofline": {"bound": "hbm", "kernel": "k_quant_hull_idx", "achieved": alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9,
+                         "unit": "GB/s", "frac": alg / (ms * 1e-3) / HBM_PEAK, "algorithmic_bytes_per_launch": alg, "avg_launch_ms": ms},
+            "parity_vs_oracle_on_sample": ok,
+            "workload": f"kodak24_c256: {desc}; one pass of quantize(mu, sigma, lmbda) over the {L}-point sweep, raw code lengths, "
+                        f"channel-major planes in, rank indices out"}
 
 
 def run_notebook(args, torch, dev, workload=None, steps=None, warmup=None, cpu=True):

@@ -368,3 +368,90 @@ def test_notebook_threshold_kernel_guard_machinery():
     assert rc1 == 0, out1
     rc2, out2 = run(2)
     assert rc2 == 1, out2
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# K1e: rank indices of a raw-length lambda sweep (16 to 32 lambdas) from K1t's thresholds
+# ---------------------------------------------------------------------------------------------------------------------
+def _threshold_lambdas(mu, sg, tab, rng, count):
+    """Lambdas that sit on level-change thresholds of chosen elements: the element's own per-level distortions (the
+    reference's four rounded f32 operations, utils.py:319-320) give T_n = max_j min_i (du_i - du_j) / (j - i)."""
+    lev = O.levels_of_sorted_ranks(N)[np.argsort(np.argsort(tab, kind="stable"), kind="stable")]
+    out = []
+    for e in rng.permutation(mu.size)[:6 * count]:
+        d = np.float32(-0.5) * ((tab - mu[e]) / sg[e]) ** 2
+        du = np.array([np.float64(-d[lev == n].max()) for n in range(N + 1)])
+        T = [max(min((du[i] - du[j]) / (j - i) for i in range(n + 1)) for j in range(n + 1, N + 1)) for n in range(N)]
+        T = [t for t in T if 1e-3 < t < 50.0]
+        if T:
+            out.append(float(np.float32(T[int(rng.integers(0, len(T)))])))
+    out = sorted(set(out))
+    keep = [out[0]]
+    for v in out[1:]:
+        if v > keep[-1] * 1.03:
+            keep.append(v)
+    return keep[:32]
+
+
+def test_raw_sweep_threshold_kernel(ops):
+    """K1e on K1t's adversarial inputs (exact code-point hits, mid-points, outside the table, extreme sigmas, du values that
+    are multiples of powers of two) for sweeps it takes (16-32 lambdas in any order, sorted / reversed / random / on the
+    elements' own thresholds) and sweeps it hands to k_quant_fast; odd row counts; the channel-last input form."""
+    rng = np.random.default_rng(31)
+    tab, _, _ = synth(rng, 4, 1)
+    t = np.sort(tab[0])
+    mids = (t[:-1] + t[1:]) * np.float32(0.5)
+    mu = np.concatenate([t, mids, [t[0] - 50, t[-1] + 50, 0.0], rng.normal(0, 1, 6000).astype(np.float32)]).astype(np.float32)
+    sg = np.concatenate([np.full(t.size + mids.size + 3, 1.0), np.exp(rng.normal(-2, 2.5, 6000))]).astype(np.float32)
+    sg[::7] = np.float32(0.99999994)
+    sg[5::11] = np.float32(2.0 ** -10)
+    on_thr = _threshold_lambdas(mu[-6000:], sg[-6000:], tab[0], rng, 60)
+    assert len(on_thr) >= 16
+    sweeps = [LAM32, LAM32[::-1], [LAM32[i] for i in rng.permutation(32)[:17]], [2.0 ** k for k in range(-10, 9)], on_thr,
+              [float(v) for v in np.sort(np.exp(rng.uniform(np.log(1e-3), np.log(1e3), 32)))],
+              LAM32[:15],                                            # too short        -> k_quant_fast
+              LAM32[:20] + LAM32[:3],                                # repeated values  -> k_quant_fast
+              [1e-9 * 4.0 ** k for k in range(20)]]                  # > 16 octaves     -> k_quant_fast
+    for lam in sweeps:
+        want = CO.quantize(mu[:, None], sg[:, None], tab, lam, N=N, threads=8)[:, :, 0]
+        got = ops.quantize(dev(mu), dev(sg), dev(tab), lam, N=N).cpu().numpy()
+        assert np.array_equal(got, want), lam
+        got = ops.quantize(dev(mu[:-1]), dev(sg[:-1]), dev(tab), lam, N=N).cpu().numpy()         # odd length
+        assert np.array_equal(got, want[:, :-1]), lam
+    # several channels: planes and the channel-last input form
+    tab3, mu3, sg3 = synth(rng, 3001, 5)
+    want = CO.quantize(mu3, sg3, tab3, LAM32, N=N, threads=8)                                     # [L, rows, C]
+    got = ops.quantize(dev(mu3.T), dev(sg3.T), dev(tab3), LAM32, N=N, layout="cb").cpu().numpy()
+    assert np.array_equal(got.transpose(0, 2, 1), want)
+    got = ops.quantize(dev(mu3), dev(sg3), dev(tab3), LAM32, N=N, layout="bc->cb").cpu().numpy()
+    assert np.array_equal(got.transpose(0, 2, 1), want)
+
+
+@pytest.mark.timeout(600)
+def test_raw_sweep_threshold_kernel_guard_machinery():
+    """K1e with every (element, lambda) forced through the literal scan (VBQ_FAST_DEBUG=1) still equals the oracle; with the
+    guard bands and the near-tie marks switched off (=2) mismatches appear on lambdas placed on the elements' thresholds."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, numpy as np, torch; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import test_gpu_twopass as t\n"
+            "from vbq_amd import ops\n"
+            "rng = np.random.default_rng(5)\n"
+            "tab, mu, sg = t.synth(rng, 200000, 1)\n"
+            "mu, sg = mu[:, 0], sg[:, 0]\n"
+            "lam = t._threshold_lambdas(mu[:4000], sg[:4000], tab[0], rng, 80)\n"
+            "assert len(lam) >= 16, len(lam)\n"
+            "want = t.CO.quantize(mu[:, None], sg[:, None], tab, lam, N=10, threads=8)[:, :, 0]\n"
+            "got = ops.quantize(t.dev(mu), t.dev(sg), t.dev(tab), lam, N=10).cpu().numpy()\n"
+            "print('MISMATCHES', int((got != want).sum()))\n") % (root, os.path.join(root, "tests"))
+
+    def run(dbg):
+        env = dict(os.environ, VBQ_FAST_DEBUG=str(dbg))
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=500)
+        assert r.returncode == 0, r.stdout + r.stderr[-3000:]
+        return int(r.stdout.strip().split("MISMATCHES")[-1])
+    assert run(0) == 0
+    assert run(1) == 0
+    assert run(2) > 0

@@ -71,4 +71,10 @@ int launch_level_counts_hull10(const float *mu, const float *sg, int64_t n_per_c
                                const float *table, const double *lam, int32_t L, int vec_ok,
                                unsigned long long *level_counts, hipStream_t st);
 
+// K1e (vbq_quantize_fast.hip): rank indices of a raw-length lambda sweep from K1t's thresholds; N = 10.  Returns 1 when the
+// sweep is not eligible (caller falls back to launch_quant_fast).
+int launch_quant_hull_idx10(const float *mu, const float *sg, int64_t n_per_ch, int64_t ch_stride, int32_t n_ch,
+                            const float *table, const double *lam, int32_t L, int vec_ok, uint16_t *out_idx, int64_t E,
+                            hipStream_t st);
+
 }  // namespace vbq

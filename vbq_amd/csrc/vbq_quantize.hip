@@ -432,6 +432,15 @@ int launch_quantize(const float *mu, const float *sg, int64_t n_rows, int32_t n_
                     if (r < 0) return r;
                 }
             }
+            if constexpr (sizeof(PenT) == 4 && N == 10) {
+                // a raw-length sweep with indices as the only output: thresholds, then a walk down the staircase
+                if (fast_ok && !lc_out && !len_c && oi && !oz && !ob) {
+                    const int r = launch_quant_hull_idx10(mu_r, sg_r, n_per_ch, ch_stride, n_ch, table, lc.lam, Lc,
+                                                          vec_ok | (bc_to_cb ? 2 : 0), oi, E, st);
+                    if (r == VBQ_OK) continue;
+                    if (r < 0) return r;
+                }
+            }
             if constexpr (sizeof(PenT) == 4) {
                 if (fast_ok) {
                     const int r = launch_quant_fast<N>(mu_r, sg_r, n_per_ch, ch_stride, n_ch, table, l32, len_c, Lc, oi, oz, ob,

@@ -705,6 +705,311 @@ k_level_counts_hull(const float *__restrict__ mu, const float *__restrict__ sg, 
     }
 }
 
+
+// =====================================================================================================================
+// K1e: rank INDICES for a whole lambda sweep with the raw lengths of quantizer.py:167-169, from K1t's thresholds.
+//
+// Same lines, same thresholds, same positions and guard bands as K1t; what changes is the product: not ten counter updates
+// per element but one index per (element, lambda).  The better side's rank of every level goes to a per-lane LDS column
+// rk[N - level]; every position a_n adds 1 to a 4-bit field "levels lost at sorted sweep point a_n" of a per-lane column
+// (private: no contention); the sweep is then emitted by walking the column.  The fields of a word sum to at most 10, so
+// one multiplication by 0x11111111 turns eight of them into their running sums, a shift and a v_and_or_b32 turn a sum
+// into the LDS address of rk[level], and two elements leave as one 4-byte store per lambda: ~9 instructions per lambda for
+// two elements, against ~95 in k_quant_fast.  (The notebook's f64 variant of the same idea is k_quant_notebook_hull.)
+//
+// Exactness on top of K1t's bands: WHICH SIDE of the winning level.  The reference scans [L_0..L_N, R_1..R_N] and keeps
+// the first maximum, so inside a level R wins only if fl(dR + pen) < fl(dL + pen); with dR < dL that can fail when
+// dL - dR is below an ulp of the cost.  A level n >= 1 only wins where its cost is at most level n-1's, i.e. with a cost
+// <= du_n + n du_(n-1); a right side that is better by less than 2^-19 of that marks the level, and the sweep points at
+// which a marked level wins (sorted positions a_n .. a_(n-1) - 1) are re-solved with the literal scan like the points
+// inside a guard band.  Ties between levels only occur inside bands (K1t's argument), where the literal scan applies the
+// reference's candidate order.
+#ifndef VBQ_K1E_STAGE
+#define VBQ_K1E_STAGE 5
+#endif
+#ifndef VBQ_K1E_WAVES
+#define VBQ_K1E_WAVES 4
+#endif
+template <int N>
+__global__ void __launch_bounds__(256, VBQ_K1E_WAVES)
+k_quant_hull_idx(const float *__restrict__ mu, const float *__restrict__ sg, long n_per_ch, long ch_stride, int C,
+                 const float *__restrict__ table, Lambdas32 lam, HullSweep sw, int vec_ok,
+                 uint16_t *__restrict__ out_idx, long E, int dbg) {
+    constexpr int T = table_size(N);
+    constexpr int N1 = N + 1;
+    constexpr int NE = 2;
+    constexpr int PS = (N1 + 3) & ~3;
+    constexpr int CW = 5;                                     // words of eight 4-bit fields: sorted positions 0 .. 32
+    struct Lds {
+        unsigned short rk[N1 * NE * 256];                     // rank of the better side, [N - level][element][thread]
+        float tb[T + 1];
+        float penl[kMaxLambdaChunk * PS];                     // fl32(lambda) * n in the caller's order (literal scan only)
+        unsigned char lut[kHullKeys];
+        float4 rec[34];                                       // rec[i] = { lam[i-1], lam[i], lam[i+1], - }, -big / +big outside
+        unsigned char perm_s[32];
+        unsigned int cnt[CW * NE * 256];                      // [word][element][thread]: levels lost at sorted sweep point l
+    };
+    __shared__ __align__(16) Lds lds;
+    unsigned short *rk = lds.rk;
+    float *tb = lds.tb, *penl = lds.penl;
+    unsigned char *lut = lds.lut, *perm_s = lds.perm_s;
+    float4 *rec = lds.rec;
+    unsigned int *cnt = lds.cnt;
+    const int c = blockIdx.y;
+    const int L = sw.L;
+    const unsigned int tid = threadIdx.x;
+    for (int i = tid; i < T; i += blockDim.x) tb[i] = table[(long)c * T + i];
+    for (int i = tid; i < L * PS; i += blockDim.x) {
+        const int l = i / PS, n = i - l * PS;
+        penl[i] = n < N1 ? __fmul_rn(lam.lam[l], (float)n) : 0.0f;
+    }
+    for (int b = tid; b < kHullKeys / 4; b += blockDim.x)
+        reinterpret_cast<uint32_t *>(lut)[b] = reinterpret_cast<const uint32_t *>(sw.lut)[b];
+    if (tid < 34) {
+        const int i = (int)tid;
+        auto at = [&](int l) { return l < 0 ? -kHullBig : (l < L ? sw.lam[l < 32 ? l : 31] : kHullBig); };
+        rec[i] = make_float4(at(i - 1), at(i), at(i + 1), 0.0f);
+    }
+    if (tid < 32) perm_s[tid] = sw.perm[tid];
+    for (int i = tid; i < CW * NE * 256; i += blockDim.x) cnt[i] = 0;
+    __syncthreads();
+
+    const bool force_slow = dbg == 1, never_flag = dbg == 2;
+    const uint32_t all_l = L >= 32 ? 0xffffffffu : ((1u << L) - 1u);
+    const long base = (long)c * ch_stride;
+    const long npairs = (n_per_ch + NE - 1) / NE;
+    const char *tbb = reinterpret_cast<const char *>(tb);
+    const unsigned int lane = tid & 63u;
+
+    for (long q = (long)blockIdx.x * blockDim.x + tid; q < npairs; q += (long)gridDim.x * blockDim.x) {
+        const long i0 = q * NE;
+        const bool full = (vec_ok & 1) && (i0 + NE <= n_per_ch);
+        float m4[NE], s4[NE];
+        if (vec_ok & 2) {                                      // channel-last input (VBQ_LAYOUT_BC_TO_CB), see k_quant_fast
+#pragma unroll
+            for (int k = 0; k < NE; ++k) {
+                const bool ok = i0 + k < n_per_ch;
+                m4[k] = ok ? mu[(i0 + k) * C + c] : 0.0f;
+                s4[k] = ok ? sg[(i0 + k) * C + c] : 1.0f;
+            }
+        } else if (full) {
+            const float2 mv = *reinterpret_cast<const float2 *>(mu + base + i0);
+            const float2 sv = *reinterpret_cast<const float2 *>(sg + base + i0);
+            m4[0] = mv.x; m4[1] = mv.y;
+            s4[0] = sv.x; s4[1] = sv.y;
+        } else {
+#pragma unroll
+            for (int k = 0; k < NE; ++k) {
+                const bool ok = i0 + k < n_per_ch;
+                m4[k] = ok ? mu[base + i0 + k] : 0.0f;
+                s4[k] = ok ? sg[base + i0 + k] : 1.0f;
+            }
+        }
+        // ---- phase A (as k_quant_fast): both neighbours' distortions on every level, the better side's rank
+        float du[NE][N1];
+        uint32_t tiny[NE] = {0, 0};                            // bit n: R is the better side of level n by a hair
+        {
+            uint32_t g[NE] = {0, 0};
+            double rinv[NE];
+#pragma unroll
+            for (int k = 0; k < NE; ++k) rinv[k] = __ddiv_rn(1.0, (double)s4[k]);
+#pragma unroll
+            for (int n = 0; n <= N; ++n) {
+                const int off4 = 4 * ((1 << n) - 1);
+                const int top4 = off4;                         // byte offset of the last slot of the level
+#pragma unroll
+                for (int k = 0; k < NE; ++k) {
+                    const float pj = *reinterpret_cast<const float *>(tbb + off4 + g[k]);
+                    const bool below = pj < m4[k];
+                    float dL, dR;
+                    uint32_t lo4, hi4;
+                    if (n == 0) {
+                        dL = dR = dist_cost(pj, m4[k], rinv[k]);
+                        lo4 = hi4 = 0;
+                    } else {
+                        const uint32_t G4 = g[k] + (below ? 4u : 0u);
+                        int lo = (int)G4 - 4;
+                        lo = lo < 0 ? 0 : lo;
+                        if (n == N) lo = lo > top4 - 4 ? top4 - 4 : lo;       // the deepest level's one-slot-back quirk
+                        lo4 = (uint32_t)lo;
+                        hi4 = G4 > (uint32_t)top4 ? (uint32_t)top4 : G4;
+                        dL = dist_cost(*reinterpret_cast<const float *>(tbb + off4 + lo4), m4[k], rinv[k]);
+                        dR = dist_cost(*reinterpret_cast<const float *>(tbb + off4 + hi4), m4[k], rinv[k]);
+                    }
+                    const bool r_better = dR < dL;              // strict: on equal distortions L keeps the level
+                    du[k][n] = r_better ? dR : dL;
+                    g[k] = 2 * g[k] + (below ? 4u : 0u);
+                    const uint32_t b4 = r_better ? hi4 : lo4;
+                    const uint32_t better = n < N ? (b4 << (N - n - 1)) + ((1u << (N - n)) - 1u) : (b4 >> 1);
+                    rk[((N - n) * NE + k) * 256 + tid] = (unsigned short)better;
+                    if (n >= 1) {
+                        const float bound = __fmul_rn(fmaf((float)n, du[k][n - 1], du[k][n]), 1.9073486328125e-06f);
+                        tiny[k] |= (r_better && !(__fsub_rn(dL, dR) > bound)) ? (1u << n) : 0u;
+                    }
+                }
+            }
+        }
+        // ---- thresholds, positions in the sorted sweep, guard bands (K1t), the "levels lost" column
+        uint32_t flags[NE];
+#pragma unroll
+        for (int k = 0; k < NE; ++k) {
+            const bool valid = i0 + k < n_per_ch;
+            float Pm[N1], Tn[N];
+            uint64_t near[N];
+            float big = du[k][0];
+#pragma unroll
+            for (int j = 1; j + 1 < N1; j += 2) big = vmax3(big, du[k][j], du[k][j + 1]);
+            if ((N1 & 1) == 0) big = vmax(big, du[k][N1 - 1]);
+            uint32_t fl = (!(big < kHullBig) || force_slow) ? 0xffffffffu : 0u;
+            uint64_t any_near = 0;
+#pragma unroll
+            for (int n = 0; n < N; ++n) {
+#pragma unroll
+                for (int j = n + 1; j < N1; ++j) {
+                    const float r = __fmul_rn(__fsub_rn(du[k][n], du[k][j]), 1.0f / (float)(j - n));
+                    Pm[j] = n == 0 ? r : vmin(Pm[j], r);
+                }
+                float t = Pm[n + 1];
+                {
+                    int j = n + 2;
+#pragma unroll
+                    for (; j + 1 < N1; j += 2) t = vmax3(t, Pm[j], Pm[j + 1]);
+                    if (j < N1) t = vmax(t, Pm[j]);
+                }
+                Tn[n] = vmin(t, 1.0e38f);
+            }
+            uint32_t c0[N];
+#pragma unroll
+            for (int n = 0; n < N; ++n) {
+                const int key = min(max(((int)__float_as_uint(Tn[n]) >> 16) - sw.key0, 0), sw.nkeys - 1);
+                c0[n] = lut[key];
+            }
+#pragma unroll
+            for (int h = 0; h < N; h += VBQ_K1E_STAGE) {
+                float4 nb[VBQ_K1E_STAGE];
+#pragma unroll
+                for (int i = 0; i < VBQ_K1E_STAGE; ++i) nb[i] = rec[c0[h + i]];
+#pragma unroll
+                for (int i = 0; i < VBQ_K1E_STAGE; ++i) {
+                    const int n = h + i;
+                    const float t = Tn[n];
+                    const uint32_t a = c0[n] + (nb[i].y < t ? 1u : 0u);          // lam_(a-1) < T <= lam_(a)
+                    const float G = __fmul_rn(fmaf(fabsf(t), (float)(n + 1), du[k][n]), 9.5367431640625e-07f);
+                    const float dist = vmin3abs(__fsub_rn(t, nb[i].x), __fsub_rn(t, nb[i].y), __fsub_rn(t, nb[i].z));
+                    near[n] = __builtin_amdgcn_ballot_w64(dist <= G);
+                    any_near |= near[n];
+                    atomicAdd(&cnt[((a >> 3) * NE + k) * 256 + tid], 1u << (4u * (a & 7u)));
+                }
+            }
+            if (any_near != 0) {                               // rare: list the sweep points inside the band(s)
+#pragma unroll
+                for (int n = 0; n < N; ++n) {
+                    if (near[n] == 0) continue;
+                    if ((near[n] >> lane) & 1ull) {
+                        const float G = __fmul_rn(fmaf(fabsf(Tn[n]), (float)(n + 1), du[k][n]), 9.5367431640625e-07f);
+                        for (int l = 0; l < L; ++l)
+                            fl |= (fabsf(__fsub_rn(sw.lam[l], Tn[n])) <= G) ? (1u << l) : 0u;
+                    }
+                }
+            }
+            if (__builtin_amdgcn_ballot_w64(tiny[k] != 0u) != 0ull) {      // rare: a marked level and where it wins
+                auto pos_of = [&](float t) {                   // the position of a threshold again (not kept: registers)
+                    const int key = min(max(((int)__float_as_uint(t) >> 16) - sw.key0, 0), sw.nkeys - 1);
+                    const uint32_t cc = lut[key];
+                    return cc + (rec[cc].y < t ? 1u : 0u);
+                };
+#pragma unroll
+                for (int n = 1; n <= N; ++n) {
+                    if ((tiny[k] >> n) & 1u) {
+                        const uint64_t hi = (1ull << pos_of(Tn[n - 1])) - 1ull;       // sorted points below a_(n-1)
+                        const uint64_t lo = n < N ? (1ull << pos_of(Tn[n < N ? n : 0])) - 1ull : 0ull;
+                        fl |= (uint32_t)(hi & ~lo);
+                    }
+                }
+            }
+            flags[k] = (valid && !never_flag) ? (fl & all_l) : 0u;
+        }
+        // ---- emit the sweep (see k_quant_notebook_hull): level index r = N - level only grows along the sorted sweep
+        uint32_t cw[CW][NE];
+#pragma unroll
+        for (int wd = 0; wd < CW; ++wd)
+            if (wd * 8 <= L) {
+#pragma unroll
+                for (int k = 0; k < NE; ++k) cw[wd][k] = atomicExch(&cnt[(wd * NE + k) * 256 + tid], 0u);    // read and clear
+            }
+        uint16_t *oi = out_idx + base + i0;
+        if (full) {
+            const char *rkb = reinterpret_cast<const char *>(rk);
+            uint32_t lbase[NE], run[NE] = {0, 0};
+#pragma unroll
+            for (int k = 0; k < NE; ++k) lbase[k] = (k * 256 + tid) * 2;           // bits 0 .. 9; the level index goes into bits 10 .. 13
+            const int nfull = L >> 3;
+#pragma unroll
+            for (int wd = 0; wd < CW - 1; ++wd) {
+                if (wd > nfull) break;
+                const uint2 pw = reinterpret_cast<const uint2 *>(sw.perm)[wd];      // eight plane numbers, one scalar load
+                uint32_t P[NE];
+#pragma unroll
+                for (int k = 0; k < NE; ++k) {
+                    P[k] = (cw[wd][k] + run[k]) * 0x11111111u;
+                    run[k] = P[k] >> 28;
+                }
+                auto addr = [&](int j, int k) {
+                    const uint32_t sh = j < 3 ? (P[k] << (10 - 4 * j)) : (P[k] >> (4 * j - 10));
+                    return (sh & 0x3c00u) | lbase[k];
+                };
+                auto plane = [&](int j) { return ((j < 4 ? pw.x : pw.y) >> (8 * (j & 3))) & 0xffu; };
+                if (wd < nfull) {                                                     // a whole word: eight sweep points, no tests
+                    uint32_t rank[8][NE];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+#pragma unroll
+                        for (int k = 0; k < NE; ++k) rank[j][k] = *reinterpret_cast<const unsigned short *>(rkb + addr(j, k));
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        *reinterpret_cast<uint32_t *>(oi + (long)plane(j) * E) = rank[j][0] | (rank[j][1] << 16);
+                } else {
+                    const int lim = L - wd * 8;
+#pragma unroll
+                    for (int j = 0; j < 7; ++j) {
+                        if (j >= lim) break;
+                        *reinterpret_cast<uint32_t *>(oi + (long)plane(j) * E) =
+                            *reinterpret_cast<const unsigned short *>(rkb + addr(j, 0)) |
+                            ((uint32_t)*reinterpret_cast<const unsigned short *>(rkb + addr(j, 1)) << 16);
+                    }
+                }
+            }
+        } else {
+            uint32_t r[NE] = {0, 0};
+            for (int l = 0; l < L; ++l) {
+#pragma unroll
+                for (int k = 0; k < NE; ++k) {
+                    uint32_t w = 0;
+#pragma unroll
+                    for (int wd = 0; wd < CW - 1; ++wd) w = (l >> 3) == wd ? cw[wd][k] : w;
+                    r[k] += (w >> (4 * (l & 7))) & 15u;
+                    if (i0 + k < n_per_ch) oi[(long)sw.perm[l] * E + k] = rk[(r[k] * NE + k) * 256 + tid];
+                }
+            }
+        }
+        // ---- sweep points inside a guard band or won by a marked level: literal scan, result overwrites the emitted one
+        if (__builtin_amdgcn_ballot_w64((flags[0] | flags[1]) != 0u) != 0ull) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the emitted values have landed before they are replaced
+#pragma unroll
+            for (int k = 0; k < NE; ++k) {
+                while (__builtin_amdgcn_ballot_w64(flags[k] != 0u) != 0ull) {
+                    if (flags[k] != 0u) {
+                        const int l = __builtin_ctz(flags[k]);
+                        flags[k] &= flags[k] - 1u;
+                        const int lo_ = perm_s[l];
+                        oi[(long)lo_ * E + k] = (uint16_t)exact_rank_scan<N>(tb, m4[k], s4[k], penl + lo_ * PS);
+                    }
+                }
+            }
+        }
+    }
+}
+
 }  // namespace
 
 template <int N>
@@ -748,15 +1053,10 @@ int launch_quant_fast(const float *mu, const float *sg, int64_t n_per_ch, int64_
     return VBQ_OK;
 }
 
-// Host side of K1t: sort the sweep, check that the bucket table applies (distinct f32 values at least one bucket
-// apart, within 16 octaves), launch.  Returns 1 when the sweep is not eligible (the caller then takes the dense
-// counting kernel), VBQ_OK / an error otherwise.
-int launch_level_counts_hull10(const float *mu, const float *sg, int64_t n_per_ch, int64_t ch_stride, int32_t n_ch,
-                               const float *table, const double *lam, int32_t L, int vec_ok,
-                               unsigned long long *level_counts, hipStream_t st) {
-    static const bool off = [] { const char *e = getenv("VBQ_NO_HULL"); return e && e[0] == '1'; }();
-    if (off || L < 1 || L > 32) return 1;
-    HullSweep sw;
+// Sort the sweep by its f32 values and build the bucket table.  false: the sweep is not eligible for the threshold kernels
+// (more than 32 values, a value outside the fast kernels' range, two values in one bucket, more than 16 octaves).
+static bool build_hull_sweep(const double *lam, int L, HullSweep &sw) {
+    if (L < 1 || L > 32) return false;
     int order[32];
     for (int i = 0; i < L; ++i) order[i] = i;
     for (int i = 1; i < L; ++i)                              // insertion sort by the f32 value
@@ -765,11 +1065,11 @@ int launch_level_counts_hull10(const float *mu, const float *sg, int64_t n_per_c
     for (int i = 0; i < 32; ++i) { sw.lam[i] = kHullBig; sw.perm[i] = 0; }
     for (int i = 0; i < L; ++i) {
         const float v = (float)lam[order[i]];
-        if (!(v >= 1.9e-12f && v <= 1.8e19f)) return 1;
+        if (!(v >= 1.9e-12f && v <= 1.8e19f)) return false;
         uint32_t bits;
         memcpy(&bits, &v, 4);
         const int key = (int)(bits >> 16);
-        if (key <= prev_key) return 1;                        // two sweep points in one bucket (or equal): dense kernel
+        if (key <= prev_key) return false;                    // two sweep points in one bucket (or equal): dense kernel
         prev_key = key;
         sw.lam[i] = v;
         sw.perm[i] = (unsigned char)order[i];
@@ -779,18 +1079,29 @@ int launch_level_counts_hull10(const float *mu, const float *sg, int64_t n_per_c
     sw.key0 = (int)(b0 >> 16);
     sw.nkeys = prev_key - sw.key0 + 2;
     sw.L = L;
-    if (sw.nkeys > kHullKeys) return 1;
-    {
-        int l = 0;
-        for (int b = 0; b < kHullKeys; ++b) {
-            while (l < L) {
-                uint32_t bits;
-                memcpy(&bits, &sw.lam[l], 4);
-                if ((int)(bits >> 16) < sw.key0 + b) ++l; else break;
-            }
-            sw.lut[b] = (unsigned char)l;
+    if (sw.nkeys > kHullKeys) return false;
+    int l = 0;
+    for (int b = 0; b < kHullKeys; ++b) {
+        while (l < L) {
+            uint32_t bits;
+            memcpy(&bits, &sw.lam[l], 4);
+            if ((int)(bits >> 16) < sw.key0 + b) ++l; else break;
         }
+        sw.lut[b] = (unsigned char)l;
     }
+    return true;
+}
+
+// Host side of K1t: sort the sweep, check that the bucket table applies (distinct f32 values at least one bucket
+// apart, within 16 octaves), launch.  Returns 1 when the sweep is not eligible (the caller then takes the dense
+// counting kernel), VBQ_OK / an error otherwise.
+int launch_level_counts_hull10(const float *mu, const float *sg, int64_t n_per_ch, int64_t ch_stride, int32_t n_ch,
+                               const float *table, const double *lam, int32_t L, int vec_ok,
+                               unsigned long long *level_counts, hipStream_t st) {
+    static const bool off = [] { const char *e = getenv("VBQ_NO_HULL"); return e && e[0] == '1'; }();
+    if (off || L < 1 || L > 32) return 1;
+    HullSweep sw;
+    if (!build_hull_sweep(lam, L, sw)) return 1;
     const int64_t nquads = (n_per_ch + VBQ_HULL_NE - 1) / VBQ_HULL_NE;
     int64_t gx = (nquads + kHullThreads - 1) / kHullThreads;
     static const int rounds = [] { const char *e = getenv("VBQ_HULL_ROUNDS"); return e ? atoi(e) : 1; }();
@@ -814,6 +1125,30 @@ int launch_level_counts_hull10(const float *mu, const float *sg, int64_t n_per_c
     hipLaunchKernelGGL((k_level_counts_hull<10>), dim3((unsigned)gx, (unsigned)n_ch), dim3(kHullThreads), 0, st, mu, sg,
                        (long)n_per_ch, (long)ch_stride, (int)n_ch, table, l32, sw, vec_ok, level_counts, dbg);
     VBQ_CHECK_LAUNCH("level_counts_hull");
+    return VBQ_OK;
+}
+
+// Host side of K1e.  Returns 1 when the sweep is not eligible (the caller takes k_quant_fast).
+int launch_quant_hull_idx10(const float *mu, const float *sg, int64_t n_per_ch, int64_t ch_stride, int32_t n_ch,
+                            const float *table, const double *lam, int32_t L, int vec_ok, uint16_t *out_idx, int64_t E,
+                            hipStream_t st) {
+    static const bool off = [] { const char *e = getenv("VBQ_NO_HULL"); return e && e[0] == '1'; }();
+    if (off || L < 16) return 1;                             // below that the thresholds cost more than the solves they replace
+                                                             // (Kodak-24: 0.25 against 0.27 ms at 16 lambdas, 0.29 against 0.43 at 32)
+    HullSweep sw;
+    if (!build_hull_sweep(lam, L, sw)) return 1;
+    const int64_t npairs = (n_per_ch + 1) / 2;
+    int64_t gx = (npairs + 255) / 256;
+    static const int rounds = [] { const char *e = getenv("VBQ_HULL_ROUNDS"); return e ? atoi(e) : 2; }();
+    int64_t cap = (int64_t)256 * VBQ_K1E_WAVES * rounds / n_ch;          // VBQ_K1E_WAVES workgroups per CU resident
+    if (cap < 1) cap = 1;
+    if (gx > cap) gx = cap;
+    static const int dbg = [] { const char *e = getenv("VBQ_FAST_DEBUG"); return e ? atoi(e) : 0; }();
+    Lambdas32 l32;
+    for (int i = 0; i < kMaxLambdaChunk; ++i) l32.lam[i] = i < L ? (float)lam[i] : 0.0f;
+    hipLaunchKernelGGL((k_quant_hull_idx<10>), dim3((unsigned)gx, (unsigned)n_ch), dim3(256), 0, st, mu, sg, (long)n_per_ch,
+                       (long)ch_stride, (int)n_ch, table, l32, sw, vec_ok, out_idx, (long)E, dbg);
+    VBQ_CHECK_LAUNCH("quant_hull_idx");
     return VBQ_OK;
 }
 
