@@ -702,7 +702,7 @@ int launch_notebook_hull10(const float *means, const float *stds, int64_t n, con
     sw.var_lo = fmaxf(4e-38f / sw.b[0], 1e-30f);
     sw.var_hi = fminf(1e38f / sw.b[Lc - 1], 1e30f);
     int64_t gx = ((n + 1) / 2 + 255) / 256;
-    static const int rounds = [] { const char *e = getenv("VBQ_HULL_ROUNDS"); return e ? atoi(e) : 2; }();
+    constexpr int rounds = 2;                               // grid = this many times the resident workgroups (measured)
     const int64_t cap = 256 * (ov ? 2 : (Lc <= 32 ? 4 : 3)) * rounds;              // persistent grid: every CU's resident workgroups, two rounds
     if (gx > cap) gx = cap;
     if (gx < 1) gx = 1;

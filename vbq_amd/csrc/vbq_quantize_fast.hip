@@ -1104,7 +1104,7 @@ int launch_level_counts_hull10(const float *mu, const float *sg, int64_t n_per_c
     if (!build_hull_sweep(lam, L, sw)) return 1;
     const int64_t nquads = (n_per_ch + VBQ_HULL_NE - 1) / VBQ_HULL_NE;
     int64_t gx = (nquads + kHullThreads - 1) / kHullThreads;
-    static const int rounds = [] { const char *e = getenv("VBQ_HULL_ROUNDS"); return e ? atoi(e) : 1; }();
+    constexpr int rounds = 1;                               // grid = this many times the resident workgroups (measured)
     int64_t cap = (int64_t)256 * VBQ_HULL_WAVES * rounds * 256 / kHullThreads / n_ch;    // VBQ_HULL_WAVES x 4 waves per CU resident
     if (cap < 1) cap = 1;
     if (gx > cap) {
@@ -1139,7 +1139,7 @@ int launch_quant_hull_idx10(const float *mu, const float *sg, int64_t n_per_ch, 
     if (!build_hull_sweep(lam, L, sw)) return 1;
     const int64_t npairs = (n_per_ch + 1) / 2;
     int64_t gx = (npairs + 255) / 256;
-    static const int rounds = [] { const char *e = getenv("VBQ_HULL_ROUNDS"); return e ? atoi(e) : 2; }();
+    constexpr int rounds = 2;                               // grid = this many times the resident workgroups (measured)
     int64_t cap = (int64_t)256 * VBQ_K1E_WAVES * rounds / n_ch;          // VBQ_K1E_WAVES workgroups per CU resident
     if (cap < 1) cap = 1;
     if (gx > cap) gx = cap;
