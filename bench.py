@@ -287,6 +287,12 @@ def run_workload(name, args, torch, dist, dev, rank, world, steps, warmup, detai
                      "pass_ms": k1_ms, "latents_per_s_kernel_only": E * L / (k1_ms * 1e-3),
                      # what actually bounds the kernel: share of the SIMDs' issue cycles spent on its VALU instructions
                      "valu_issue_frac": (valu or {}).get("valu_issue_frac"), "valu": valu,
+                     # the north star's "HBM-read roofline" prices the UNFUSED per-lambda call, 8 B read per latent,
+                     # i.e. a ceiling of 1.0e12 latents/s at 8 TB/s (target 60 % = 6.0e11).  The fused kernels read every element
+                     # once per sweep, so this is a throughput ratio against that ceiling, not a bandwidth fraction.
+                     "per_lambda_read_roofline": {"bytes_read_per_latent": 8, "ceiling_latents_per_s": HBM_PEAK / 8.0,
+                                                  "kernel_frac": E * L / (k1_ms * 1e-3) / (HBM_PEAK / 8.0),
+                                                  "step_frac_per_gpu": 2 * E * L * steps / dt / (HBM_PEAK / 8.0)},
                      "note": "K2 of the previous row chunk runs concurrently on a second stream" if k1_n > 1 else None},
         "stages_ms": {"layout_change": timers.total_ms("layout") / steps if C > 1 else None,
                       "pass1_k1t_solve_and_level_histogram": k1h_ms, "pass2_k1_solve": k1_ms,

@@ -440,7 +440,7 @@ k_quant_fast(const float *__restrict__ mu, const float *__restrict__ sg, long n_
 // so the rounded comparison and the real one agree whenever that distance exceeds 2^-22 of the envelope's height, which
 // level n's own line bounds from above.  Thresholds computed in f32 carry a relative error below 2^-22 (max / min commute
 // with the monotone map x -> x (1 +- d)).  Hence: the two sweep points next to every threshold are tested against the
-// guard band  2^-21 (du_n + lambda (n + 1));  a sweep point inside a band -- or any non-finite cost -- is re-solved for
+// guard band  2^-20 (du_n + |T_n| (n + 1));  a sweep point inside a band -- or any non-finite cost -- is re-solved for
 // that element with the literal 21-candidate scan and the histogram corrected by (+1 exact level, -1 predicted level).
 // About 1 threshold in 10 000 takes that path (Kodak-24 sweep: 9 010 of 3.0e8 (element, lambda) pairs, 8 levels changed).  tests/test_gpu_twopass.py forces it (exact ties, equal
 // costs, thresholds on sweep points) and tools/stress_parity.py --levels compares 1e9+ solves with the C oracle.
