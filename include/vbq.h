@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define VBQ_ABI_VERSION 2
+#define VBQ_ABI_VERSION 3
 
 enum {
     VBQ_OK = 0,
@@ -286,6 +286,13 @@ int vbq_gather_f32(const uint16_t *d_idx, int64_t n_rows, int32_t n_ch, int32_t 
  * workgroup works on ONE channel (one 8 KB table in LDS, wave-uniform penalties).
  * ---------------------------------------------------------------------------------- */
 int vbq_transpose_f32(const float *d_in, int64_t n_rows, int64_t n_cols, float *d_out, void *stream);
+
+/* The same for a stack of planes of 2- or 4-byte elements: out[b][c][r] = in[b][r][c] for b < n_batch.  With
+ * elem_bytes = 2 it hands the u16 rank indices of the plane kernels ([n_lambda][n_ch][n_rows]) back in the caller's
+ * channel-last layout ([n_lambda][n_rows][n_ch], the shape of compress_batch_channel_latents' results,
+ * quantizer.py:186-188); with 4, Z_hat / num_bits planes.  n_batch <= 65535. */
+int vbq_transpose_planes(const void *d_in, int64_t n_batch, int64_t n_rows, int64_t n_cols, int32_t elem_bytes,
+                         void *d_out, void *stream);
 
 /* ----------------------------------------------------------------------------------
  * K4  BMSHJ2018 prior (learned_prior.py).  Parameters are the EFFECTIVE ones --

@@ -24,7 +24,7 @@ def built_lib():
 def test_header_declares_the_expected_entry_points():
     names = declared_functions()
     for must in ("vbq_quantize_f32", "vbq_quantize_notebook_f64", "vbq_histogram_u16", "vbq_histogram_u16_i32", "vbq_moments_f32",
-                 "vbq_transpose_f32",
+                 "vbq_transpose_f32", "vbq_transpose_planes",
                  "vbq_gather_f32", "vbq_argmax_candidates_f32", "vbq_bmshj_cdf_pdf_f32", "vbq_bmshj_icdf_step_f32", "vbq_bmshj_nll_grad_f32", "vbq_rans_encode_u16", "vbq_rans_decode_u16", "vbq_uniform_quantize_f32", "vbq_nearest_code_f64",
            "vbq_analogy_ranks_workspace_bytes", "vbq_analogy_ranks_f32", "vbq_image_sqerr_u8", "vbq_u8_to_f64",
            "vbq_pack_counts_3x21", "vbq_unpack_counts_3x21", "vbq_ssim_scale_workspace_bytes", "vbq_ssim_scale_f64", "vbq_downsample2_f64",
@@ -44,7 +44,7 @@ def test_ctypes_binding_matches_header(built_lib):
     from vbq_amd import _lib
     assert sorted(_lib.SIGNATURES) == declared_functions()
     h = _lib.lib()
-    assert h.vbq_abi_version() == 2
+    assert h.vbq_abi_version() == 3
     assert isinstance(h.vbq_device_count(), int)
     # argument validation happens before any device work: callable without a GPU
     assert h.vbq_quantize_workspace_bytes(256, 32, 10) >= 256 * 32 * 11 * 4

@@ -195,6 +195,68 @@ def test_quantize_facade():
     assert abs(lag - lag_ref) <= 1e-5 * abs(lag_ref)
 
 
+def test_quantize_facade_channel_last_takes_the_plane_kernels(monkeypatch):
+    """vbq_amd.quantize(mu[B, C], sigma[B, C], lmbda, table=...) -- the literal north-star call on latents as they arrive
+    (quantizer.py:90-91): transposes + plane kernels + one batched transpose back, results in the caller's layout, equal to
+    the oracle; the table is validated once per object, not per call."""
+    import vbq_amd
+    from vbq_amd import api, ops
+    rng = np.random.default_rng(21)
+    B, C = 777, 24                                            # odd row count: the scalar transpose paths
+    s_c = np.exp(rng.uniform(np.log(0.3), np.log(3.0), C))
+    mu = (rng.standard_normal((B, C)) * s_c).astype(np.float32)
+    sg = np.exp(rng.normal(-2, 0.7, (B, C))).astype(np.float32)
+    tab = vbq_amd.gaussian_table(s_c, N)
+    lam = [float(v) for v in 2.0 ** np.linspace(-8, 7.5, 32)]
+    wi, wz, wb = CO.quantize(mu, sg, tab, lam, N=N, want_zhat=True, want_bits=True)
+    calls = []
+    real = ops.quantize
+    monkeypatch.setattr(ops, "quantize", lambda *a, **k: (calls.append(k.get("layout")), real(*a, **k))[1])
+    idx = vbq_amd.quantize(mu, sg, lam, table=tab)            # raw-length sweep of 32: K1e on planes
+    assert calls == ["cb"]
+    assert idx.shape == (32, B, C) and idx.dtype == np.uint16 and np.array_equal(idx, wi)
+    mu_d, sg_d, tab_d = (torch.from_numpy(a).cuda() for a in (mu, sg, tab))
+    i2, z2, b2 = vbq_amd.quantize(mu_d, sg_d, lam[:5], table=tab_d, return_values=True, return_bits=True)
+    assert i2.is_cuda and tuple(i2.shape) == (5, B, C)
+    assert np.array_equal(i2.cpu().numpy(), wi[:5]) and np.array_equal(z2.cpu().numpy(), wz[:5]) and np.array_equal(b2.cpu().numpy(), wb[:5])
+    one = vbq_amd.quantize(mu_d, sg_d, lam[7], table=tab_d)
+    assert tuple(one.shape) == (B, C) and np.array_equal(one.cpu().numpy(), wi[7])
+    ll = (np.arange(N + 1, dtype=np.float32) + np.abs(rng.normal(0, 1, (3, C, N + 1)))).astype(np.float32)
+    i3 = vbq_amd.quantize(mu_d, sg_d, lam[10:13], table=tab_d, lengths=ll)
+    assert np.array_equal(i3.cpu().numpy(), CO.quantize(mu, sg, tab, lam[10:13], N=N, level_len=ll))
+    icb = vbq_amd.quantize(mu_d.t().contiguous(), sg_d.t().contiguous(), lam[:3], table=tab_d, layout="cb")
+    assert np.array_equal(icb.cpu().numpy().transpose(0, 2, 1), wi[:3])
+    # the table check runs once per table object: the second call with the same tensor does not copy it to the host
+    key_hits = len(api._CHECKED)
+    copies = []
+    real_cpu = torch.Tensor.cpu
+    monkeypatch.setattr(torch.Tensor, "cpu", lambda t, *a, **k: (copies.append(tuple(t.shape)), real_cpu(t, *a, **k))[1])
+    vbq_amd.quantize(mu_d, sg_d, lam[:2], table=tab_d)
+    monkeypatch.setattr(torch.Tensor, "cpu", real_cpu)
+    assert (C, 2 ** (N + 1) - 1) not in copies and len(api._CHECKED) == key_hits
+    bad = tab.copy()
+    bad[3, 5] = 1e9                                           # level 2's points no longer ascend
+    with pytest.raises(ValueError):
+        vbq_amd.quantize(mu, sg, 1.0, table=bad)
+    assert vbq_amd.quantize(mu, sg, 1.0, table=bad, validate=False).shape == (B, C)   # the caller's responsibility then
+    tab_d[3, 5] = 1e9                                         # an in-place edit of a checked tensor is checked again
+    with pytest.raises(ValueError):
+        vbq_amd.quantize(mu_d, sg_d, 1.0, table=tab_d)
+
+
+def test_transpose_planes_u16_and_f32():
+    from vbq_amd import ops
+    rng = np.random.default_rng(2)
+    for shape in ((3, 64, 128), (2, 37, 53), (5, 8, 8), (1, 1, 7), (4, 256, 1536)):
+        x = torch.from_numpy(rng.integers(0, 2047, shape).astype(np.uint16)).cuda()
+        got = ops.transpose_planes(x)
+        assert np.array_equal(got.cpu().numpy(), x.cpu().numpy().transpose(0, 2, 1))
+        f = torch.from_numpy(rng.standard_normal(shape).astype(np.float32)).cuda()
+        assert torch.equal(ops.transpose_planes(f), f.permute(0, 2, 1).contiguous())
+    with pytest.raises(ValueError):
+        ops.transpose_planes(torch.zeros((4, 4), dtype=torch.float32, device="cuda"))
+
+
 def _torch_nll(raw, x):
     """f64 torch restatement of loss = -mean(log(pdf + 1e-10)) with pdf = d cdf / dx by autograd
     (learned_prior.py:150-171, 405-408): the independent reference for the hand-written gradient."""

@@ -20,7 +20,6 @@ VARIANT_SOURCES = ["vbq_quantize_fast.hip", "vbq_notebook.hip", "vbq_hist.hip"]
 
 
 def one(tag, flags):
-    B.build_hip()
     objdir = os.path.join(B.LIBDIR, "obj")
     vdir = os.path.join(ROOT, "tools", "bin", "obj_" + tag)
     os.makedirs(vdir, exist_ok=True)
@@ -29,7 +28,7 @@ def one(tag, flags):
         base = s[:-4] + ".o"
         if s in VARIANT_SOURCES:
             o = os.path.join(vdir, base)
-            B._compile_one("hipcc", os.path.join(B.CSRC, s), o, flags)
+            B._compile_one("hipcc", os.path.join(B.CSRC, s), o, flags + B.extra_flags())
             objs.append(o)
         else:
             objs.append(os.path.join(objdir, base))
@@ -45,6 +44,7 @@ def main():
     for a in sys.argv[1:]:
         tag, _, fl = a.partition(":")
         specs.append((tag, [f for f in fl.split(",") if f]))
+    B.build_hip()
     with ThreadPoolExecutor(max_workers=4) as ex:
         for out in ex.map(lambda s: one(*s), specs):
             print(out)

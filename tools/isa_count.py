@@ -70,6 +70,9 @@ def main():
         if not s or s.startswith(";") or s.startswith("."):
             continue
         blocks[cur].append(s.split()[0])
+        if s.startswith(("s_cbranch", "s_branch", "s_setpc", "s_endpgm")):     # a branch ends the block even without a label
+            cur = (cur[0], cur[1] + "+")
+            blocks[cur] = []
     per_fn = collections.OrderedDict()
     for (f, b), ins in blocks.items():
         per_fn.setdefault(f, []).append((b, ins))

@@ -38,13 +38,28 @@ def hip_sources():
     return [os.path.join(CSRC, s) for s in HIP_SOURCES if os.path.exists(os.path.join(CSRC, s))]
 
 
+def _tmp(path):
+    # several ranks (or threads) may find a stale library at the same time: every builder writes its own temporary
+    # file and installs it with an atomic rename, so a reader never sees a half-written object or library
+    import threading
+    return f"{path}.{os.getpid()}.{threading.get_ident()}.tmp"
+
+
 def _compile_one(hipcc, src, obj, extra):
-    cmd = [hipcc] + HIPCC_FLAGS + extra + ["-I", INCLUDE, "-I", CSRC, "-c", src, "-o", obj + ".tmp"]
+    tmp = _tmp(obj)
+    cmd = [hipcc] + HIPCC_FLAGS + extra + ["-I", INCLUDE, "-I", CSRC, "-c", src, "-o", tmp]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed on " + os.path.basename(src) + ":\n" + r.stdout + r.stderr)
-    os.replace(obj + ".tmp", obj)
+    os.replace(tmp, obj)
     return " ".join(cmd)
+
+
+def extra_flags():
+    extra = os.environ.get("VBQ_EXTRA_HIPCC_FLAGS", "").split()       # developer experiments only
+    if os.environ.get("VBQ_ONLY_N10") == "1":   # the reference's bit depth alone (post_process.py:117): a third of the build time
+        extra.append("-DVBQ_ONLY_N10")
+    return extra
 
 
 def build_hip(force: bool = False, verbose: bool = False) -> str:
@@ -52,22 +67,23 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
     from concurrent.futures import ThreadPoolExecutor
     srcs = hip_sources()
     headers = [os.path.join(CSRC, "vbq_common.h"), os.path.join(INCLUDE, "vbq.h")]
-    extra = os.environ.get("VBQ_EXTRA_HIPCC_FLAGS", "").split()       # developer experiments only
-    if os.environ.get("VBQ_ONLY_N10") == "1":   # the reference's bit depth alone (post_process.py:117): a third of the build time
-        extra.append("-DVBQ_ONLY_N10")
+    extra = extra_flags()
     objdir = os.path.join(LIBDIR, "obj")
     flags_tag = os.path.join(objdir, "flags.txt")
+    lib_tag = os.path.join(LIBDIR, "flags.txt")                 # travels with the library (the object cache does not)
     tag = " ".join(HIPCC_FLAGS + extra)
     # A tree that arrived with its library but without the object cache (the GPU box: vbq_amd/lib/obj is not shipped) is up
-    # to date when the library is newer than every source: nothing to do, and nothing that needs hipcc.
-    if not force and not extra and not os.path.isdir(objdir) and not _newer(LIB, srcs + headers):
+    # to date when the library is newer than every source AND was built with these flags: nothing to do, and nothing
+    # that needs hipcc.
+    if not force and not os.path.isdir(objdir) and not _newer(LIB, srcs + headers) and \
+            os.path.exists(lib_tag) and open(lib_tag).read() == tag:
         return LIB
     os.makedirs(objdir, exist_ok=True)
     if not os.path.exists(flags_tag) or open(flags_tag).read() != tag:
         force = True
     objs = [os.path.join(objdir, os.path.basename(s)[:-4] + ".o") for s in srcs]
     todo = [(s, o) for s, o in zip(srcs, objs) if force or _newer(o, [s] + headers)]
-    if not todo and not _newer(LIB, objs):
+    if not todo and not _newer(LIB, objs) and os.path.exists(lib_tag) and open(lib_tag).read() == tag:
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
@@ -77,7 +93,7 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
             if verbose:
                 print(line)
     open(flags_tag, "w").write(tag)
-    tmp = LIB + ".tmp"
+    tmp = _tmp(LIB)
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + LINK_LIBS + ["-o", tmp]
     if verbose:
         print(" ".join(cmd))
@@ -85,6 +101,9 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
     if r.returncode != 0:
         raise RuntimeError("link failed:\n" + r.stdout + r.stderr)
     os.replace(tmp, LIB)
+    tmp = _tmp(lib_tag)
+    open(tmp, "w").write(tag)
+    os.replace(tmp, lib_tag)
     return LIB
 
 

@@ -406,6 +406,79 @@ k_transpose_v4(const float *__restrict__ in, long rows, long cols, float *__rest
     }
 }
 
+// Batched transpose of 2- or 4-byte elements: in [batch][rows][cols] -> out [batch][cols][rows], 64 x 64 tiles through LDS
+// with 16-byte global accesses on both sides (rows and cols multiples of the vector width, 16-byte aligned planes).
+// The u16 form turns the plane indices [L][C][B] of the fast kernels back into the caller's channel-last [L][B][C].
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_transpose_batched_vec(const T *__restrict__ in, long rows, long cols, T *__restrict__ out) {
+    constexpr int V = 16 / sizeof(T);                        // elements per 16-byte access
+    constexpr int VPR = 64 / V;                              // vectors per tile row
+    constexpr int PER = 64 * VPR / 256;                      // vectors per thread
+    struct alignas(16) Vec { T e[V]; };
+    __shared__ T tile[64][64 + 2];
+    in += (long)blockIdx.z * rows * cols;
+    out += (long)blockIdx.z * rows * cols;
+    const long r0 = (long)blockIdx.y * 64, c0 = (long)blockIdx.x * 64;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int i = threadIdx.x + 256 * k, lr = i / VPR, lc = (i % VPR) * V;
+        const long r = r0 + lr, c = c0 + lc;
+        if (r < rows && c < cols) {
+            const Vec v = *reinterpret_cast<const Vec *>(in + r * cols + c);
+#pragma unroll
+            for (int e = 0; e < V; ++e) tile[lr][lc + e] = v.e[e];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int i = threadIdx.x + 256 * k, lc = i / VPR, lr = (i % VPR) * V;
+        const long c = c0 + lc, r = r0 + lr;
+        if (r < rows && c < cols) {
+            Vec v;
+#pragma unroll
+            for (int e = 0; e < V; ++e) v.e[e] = tile[lr + e][lc];
+            *reinterpret_cast<Vec *>(out + c * rows + r) = v;
+        }
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_transpose_batched(const T *__restrict__ in, long rows, long cols, T *__restrict__ out) {
+    __shared__ T tile[64][65];
+    in += (long)blockIdx.z * rows * cols;
+    out += (long)blockIdx.z * rows * cols;
+    const long r0 = (long)blockIdx.y * 64, c0 = (long)blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;          // 64 x 4
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const long r = r0 + ty + 4 * k, c = c0 + tx;
+        if (r < rows && c < cols) tile[ty + 4 * k][tx] = in[r * cols + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const long c = c0 + ty + 4 * k, r = r0 + tx;
+        if (r < rows && c < cols) out[c * rows + r] = tile[tx][ty + 4 * k];
+    }
+}
+
+template <typename T>
+int launch_transpose_batched(const T *in, int64_t batch, int64_t rows, int64_t cols, T *out, hipStream_t st) {
+    constexpr int V = 16 / sizeof(T);
+    const bool vec = rows % V == 0 && cols % V == 0 && ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) == 0 &&
+                     (rows * cols * (int64_t)sizeof(T)) % 16 == 0;
+    const dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((rows + 63) / 64), (unsigned)batch);
+    if (vec)
+        hipLaunchKernelGGL((k_transpose_batched_vec<T>), grid, dim3(256), 0, st, in, (long)rows, (long)cols, out);
+    else
+        hipLaunchKernelGGL((k_transpose_batched<T>), grid, dim3(256), 0, st, in, (long)rows, (long)cols, out);
+    VBQ_CHECK_LAUNCH("transpose_planes");
+    return VBQ_OK;
+}
+
 }  // namespace
 }  // namespace vbq
 
@@ -907,6 +980,23 @@ extern "C" int vbq_gather_f32(const uint16_t *d_idx, int64_t n_rows, int32_t n_c
                        table_size(N), d_tab, (int)tab_per_lambda, d_out);
     VBQ_CHECK_LAUNCH("gather");
     return VBQ_OK;
+}
+
+extern "C" int vbq_transpose_planes(const void *d_in, int64_t n_batch, int64_t n_rows, int64_t n_cols, int32_t elem_bytes,
+                                    void *d_out, void *stream) {
+    using namespace vbq;
+    VBQ_REQUIRE(n_batch >= 0 && n_rows >= 0 && n_cols >= 0, VBQ_ERR_INVALID_ARGUMENT, "vbq_transpose_planes: bad sizes");
+    VBQ_REQUIRE(elem_bytes == 2 || elem_bytes == 4, VBQ_ERR_INVALID_ARGUMENT, "vbq_transpose_planes: elem_bytes %d (2 or 4)", elem_bytes);
+    if (n_batch == 0 || n_rows == 0 || n_cols == 0) return VBQ_OK;
+    VBQ_REQUIRE(d_in && d_out && d_in != d_out, VBQ_ERR_INVALID_ARGUMENT, "vbq_transpose_planes: null or aliased pointers");
+    VBQ_REQUIRE((n_rows + 63) / 64 <= 65535 && n_batch <= 65535, VBQ_ERR_UNSUPPORTED,
+                "vbq_transpose_planes: more than 4.19e6 rows or 65535 planes");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (elem_bytes == 2)
+        return launch_transpose_batched<uint16_t>(static_cast<const uint16_t *>(d_in), n_batch, n_rows, n_cols,
+                                                  static_cast<uint16_t *>(d_out), st);
+    return launch_transpose_batched<uint32_t>(static_cast<const uint32_t *>(d_in), n_batch, n_rows, n_cols,
+                                              static_cast<uint32_t *>(d_out), st);
 }
 
 extern "C" int vbq_transpose_f32(const float *d_in, int64_t n_rows, int64_t n_cols, float *d_out, void *stream) {

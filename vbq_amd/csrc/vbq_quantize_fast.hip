@@ -66,6 +66,30 @@ __device__ __forceinline__ float dist_cost(float P, float mu, double rinv) {
 
 __device__ __forceinline__ float min3f(float a, float b, float c) { return fminf(fminf(a, b), c); }
 
+// v_min_f32 / v_max_f32 as they are (IEEE mode: a NaN operand loses).  fminf / fmaxf make the compiler canonicalise
+// operands it cannot prove quiet (a v_max x, x in front of every second min of the threshold recurrences).
+__device__ __forceinline__ float vmin(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float vmax(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float vmin3abs(float a, float b, float c) {       // min(|a|, |b|, |c|)
+    float r;
+    asm("v_min3_f32 %0, |%1|, |%2|, |%3|" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+
 // Minimum of M values as a tree of v_min3_f32 (ceil((M-1)/2) instructions).
 template <int M>
 __device__ __forceinline__ float min_of(const float (&v)[M]) {
@@ -190,40 +214,47 @@ k_quant_fast(const float *__restrict__ mu, const float *__restrict__ sg, long n_
     const long base = (long)c * ch_stride;
     const long nquads = (n_per_ch + NE - 1) / NE;
 
-    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < nquads; q += (long)gridDim.x * blockDim.x) {
+    // (mu, sigma) of element group q.  Channel-last input [n_per_ch][C] (VBQ_LAYOUT_BC_TO_CB): element (row, c) at row * C + c;
+    // the lanes of a wave read 4 bytes from 128 different lines, but the 32 channels of a line are read by 32 workgroups in
+    // flight together, so the lines come out of L2; the outputs are planes as usual.
+    auto load_group = [&](long q, float (&m)[NE], float (&sv)[NE]) {
         const long i0 = q * NE;
-        const bool full = (vec_ok & 1) && (i0 + NE <= n_per_ch);
-        float m4[NE], s4[NE];
-        if (vec_ok & 2) {
-            // channel-last input [n_per_ch][C] (VBQ_LAYOUT_BC_TO_CB): element (row, c) at row * C + c.  The lanes
-            // of a wave read 4 bytes from 128 different lines, but the 32 channels of a line are read by 32
-            // workgroups in flight together, so the lines come out of L2; the outputs are planes as usual.
-#pragma unroll
-            for (int k = 0; k < NE; ++k) {
-                const bool ok = i0 + k < n_per_ch;
-                m4[k] = ok ? mu[(i0 + k) * C + c] : 0.0f;
-                s4[k] = ok ? sg[(i0 + k) * C + c] : 1.0f;
-            }
-        } else if (full) {
+        if (!(vec_ok & 2) && (vec_ok & 1) && (i0 + NE <= n_per_ch)) {
             if constexpr (NE == 4) {
                 const float4 mv = *reinterpret_cast<const float4 *>(mu + base + i0);
-                const float4 sv = *reinterpret_cast<const float4 *>(sg + base + i0);
-                m4[0] = mv.x; m4[1] = mv.y; m4[2] = mv.z; m4[3] = mv.w;
-                s4[0] = sv.x; s4[1] = sv.y; s4[2] = sv.z; s4[3] = sv.w;
+                const float4 s4v = *reinterpret_cast<const float4 *>(sg + base + i0);
+                m[0] = mv.x; m[1] = mv.y; m[2] = mv.z; m[3] = mv.w;
+                sv[0] = s4v.x; sv[1] = s4v.y; sv[2] = s4v.z; sv[3] = s4v.w;
             } else {
                 const float2 mv = *reinterpret_cast<const float2 *>(mu + base + i0);
-                const float2 sv = *reinterpret_cast<const float2 *>(sg + base + i0);
-                m4[0] = mv.x; m4[1] = mv.y;
-                s4[0] = sv.x; s4[1] = sv.y;
+                const float2 s2v = *reinterpret_cast<const float2 *>(sg + base + i0);
+                m[0] = mv.x; m[1] = mv.y;
+                sv[0] = s2v.x; sv[1] = s2v.y;
             }
         } else {
 #pragma unroll
             for (int k = 0; k < NE; ++k) {
                 const bool ok = i0 + k < n_per_ch;
-                m4[k] = ok ? mu[base + i0 + k] : 0.0f;
-                s4[k] = ok ? sg[base + i0 + k] : 1.0f;
+                const long at = (vec_ok & 2) ? (i0 + k) * C + c : base + i0 + k;
+                m[k] = ok ? mu[at] : 0.0f;
+                sv[k] = ok ? sg[at] : 1.0f;
             }
         }
+    };
+    const long q0 = (long)blockIdx.x * blockDim.x + threadIdx.x, qstep = (long)gridDim.x * blockDim.x;
+    float mn[NE], sn[NE];
+#pragma unroll
+    for (int k = 0; k < NE; ++k) { mn[k] = 0.0f; sn[k] = 1.0f; }
+    if (q0 < nquads) load_group(q0, mn, sn);
+    for (long q = q0; q < nquads; q += qstep) {
+        const long i0 = q * NE;
+        const bool full = (vec_ok & 1) && (i0 + NE <= n_per_ch);
+        float m4[NE], s4[NE];
+#pragma unroll
+        for (int k = 0; k < NE; ++k) { m4[k] = mn[k]; s4[k] = sn[k]; }
+        // The next group's loads go out BEFORE this group's stores: loads and stores share one in-order counter on gfx9
+        // (vmcnt), so a load issued after the last lambda's store could only be waited for together with every store.
+        if (q + qstep < nquads) load_group(q + qstep, mn, sn);
 
         // ---------------- phase A: descent, per-level best cost + packed side info ----------------
         float du[NE][N1];
@@ -263,7 +294,7 @@ k_quant_fast(const float *__restrict__ mu, const float *__restrict__ sg, long n_
                     dL = dist_cost(*reinterpret_cast<const float *>(tbb + off4 + lo4), m4[k], rinv[k]);
                     dR = dist_cost(*reinterpret_cast<const float *>(tbb + off4 + hi4), m4[k], rinv[k]);
                 }
-                du[k][n] = fminf(dL, dR);
+                du[k][n] = vmin(dL, dR);                        // no canonicalising v_max x, x in front (fminf: two per level)
                 g[k] = 2 * g[k] + (below ? 4u : 0u);
                 if (COUNT) continue;                           // the level alone is wanted: no rank, no gap
                 const bool r_better = dR < dL;                  // strict: on equal costs L keeps the level
@@ -461,29 +492,6 @@ constexpr int kHullKeys = 2048;         // 16 octaves of 128 buckets
 #ifndef VBQ_ABL
 #define VBQ_ABL 0                       // timing ablations of K1t (tools/build_variants.py); wrong results when != 0
 #endif
-// v_min_f32 / v_max_f32 as they are (IEEE mode: a NaN operand loses).  fminf / fmaxf make the compiler canonicalise
-// operands it cannot prove quiet (a v_max x, x in front of every second min of the threshold recurrences).
-__device__ __forceinline__ float vmin(float a, float b) {
-    float r;
-    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ float vmax(float a, float b) {
-    float r;
-    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ float vmax3(float a, float b, float c) {
-    float r;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-__device__ __forceinline__ float vmin3abs(float a, float b, float c) {       // min(|a|, |b|, |c|)
-    float r;
-    asm("v_min3_f32 %0, |%1|, |%2|, |%3|" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-
 struct HullSweep {
     float lam[32];          // the sweep rounded to f32, ascending
     unsigned char perm[32]; // position of lam[l] in the caller's order
@@ -491,6 +499,160 @@ struct HullSweep {
     unsigned char lut[kHullKeys];   // lut[b] = #{ l : lam[l] below the lower edge of bucket b }
 };
 constexpr float kHullBig = 3.0e38f;
+
+// Distortion of the NEARER neighbour of z on every bit level (du is monotone in |P - z|, so one exact quotient per level).
+// The visited point is one neighbour of z on its level; the other one sits on z's side of it (the same point again at the
+// rim: the deepest level's one-slot-back quirk, quantizer.py:54-57, only ever moves the FARTHER candidate, which a minimum
+// does not see).
+template <int N>
+__device__ __forceinline__ void hull_du_nearest(const char *tbb, float z, float sigma, float (&du)[N + 1]) {
+    uint32_t g = 0;
+    const double rinv = __ddiv_rn(1.0, (double)sigma);
+#pragma unroll
+    for (int n = 0; n <= N; ++n) {
+        const int off4 = 4 * ((1 << n) - 1);
+        const int top4 = off4;
+        const float pj = *reinterpret_cast<const float *>(tbb + off4 + g);
+        const bool below = pj < z;
+        float dmin;
+        if (n == 0) {
+            dmin = __fsub_rn(pj, z);
+        } else {
+            int o4 = (int)g + (below ? 4 : -4);
+            o4 = o4 < 0 ? 0 : (o4 > top4 ? top4 : o4);
+            const float po = *reinterpret_cast<const float *>(tbb + off4 + o4);
+            dmin = fminf(fabsf(__fsub_rn(pj, z)), fabsf(__fsub_rn(po, z)));
+        }
+        const float t = (float)__dmul_rn((double)dmin, rinv);
+        du[n] = __fmul_rn(0.5f, __fmul_rn(t, t));
+        g = 2 * g + (below ? 4u : 0u);
+    }
+}
+
+// The ten thresholds T_n = max_{j > n} min_{i <= n} (du_i - du_j) / (j - i) of an element, clamped into the tables' range
+// (inf / NaN only come from non-finite costs, which are flagged separately).
+template <int N>
+__device__ __forceinline__ void hull_thresholds(const float (&du)[N + 1], float (&Tn)[N]) {
+    constexpr int N1 = N + 1;
+    float Pm[N1];                                              // Pm[j] = min_{i <= n} (du_i - du_j) / (j - i)
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+#pragma unroll
+        for (int j = n + 1; j < N1; ++j) {
+            const float r = __fmul_rn(__fsub_rn(du[n], du[j]), 1.0f / (float)(j - n));
+            Pm[j] = n == 0 ? r : vmin(Pm[j], r);
+        }
+        float t = Pm[n + 1];
+        int j = n + 2;
+#pragma unroll
+        for (; j + 1 < N1; j += 2) t = vmax3(t, Pm[j], Pm[j + 1]);
+        if (j < N1) t = vmax(t, Pm[j]);
+        Tn[n] = vmin(t, 1.0e38f);
+    }
+}
+
+template <int N>
+__device__ __forceinline__ float hull_max_du(const float (&du)[N + 1]) {
+    constexpr int N1 = N + 1;
+    float big = du[0];
+#pragma unroll
+    for (int j = 1; j + 1 < N1; j += 2) big = vmax3(big, du[j], du[j + 1]);
+    if ((N1 & 1) == 0) big = vmax(big, du[N1 - 1]);
+    return big;
+}
+
+// Position of a threshold in the sorted sweep, a = #{ l : lam_(l) < T }: bucket of the threshold's bit pattern (an
+// arithmetic shift keeps T <= 0 negative, so one median clamps "below the sweep", "above it" and the table range), then the
+// one sweep point that may share the bucket.  nb = { lam_(cnt-1), lam_(cnt), lam_(cnt+1) }: T lies between the outer two,
+// so its distance to the sweep is the smallest of the three distances.
+__device__ __forceinline__ uint32_t hull_position(float t, int key0, int nkeys, const unsigned char *lut, const float4 *rec,
+                                                  float4 &nb) {
+    const int key = min(max(((int)__float_as_uint(t) >> 16) - key0, 0), nkeys - 1);    // v_med3_i32
+    const uint32_t cnt = lut[key];
+    nb = rec[cnt];
+    return cnt + (nb.y < t ? 1u : 0u);                        // lam_(a-1) < T <= lam_(a)
+}
+
+// Guard band |lambda - T_n| <= 2^-20 (du_n + |T_n| (n + 1)): every sweep point outside it is decided by the lines.
+__device__ __forceinline__ float hull_band(float t, int n, float du_n) {
+    return __fmul_rn(fmaf(fabsf(t), (float)(n + 1), du_n), 9.5367431640625e-07f);
+}
+
+// Bit level of the winner at one sweep point from the per-level best distortions (the counting kernels' question: which
+// SIDE wins never changes the level).  multi: several levels attain the minimum, the reference's candidate order decides.
+template <int N>
+__device__ __forceinline__ uint32_t level_of_min(const float (&du)[N + 1], const float *pen, bool &multi) {
+    constexpr int N1 = N + 1;
+    float cst[N1];
+#pragma unroll
+    for (int n = 0; n < N1; ++n) cst[n] = __fadd_rn(du[n], pen[n]);
+    const float S = min_of<N1>(cst);
+    uint32_t ne = 0;                                           // bit n set <=> cost_n != S
+#pragma unroll
+    for (int n = N; n >= 0; --n) ne = __builtin_amdgcn_alignbit(ne, __float_as_uint(__fsub_rn(S, cst[n])), 31);
+    multi = (uint32_t)__popc(ne) != (uint32_t)N;
+    return (uint32_t)__builtin_ctz(~ne);
+}
+
+// Rare path of K1t for element k of the lanes in `lanes` (a sweep point inside a guard band, a non-finite cost, or the test
+// switch that sends everything here), entered once per iteration AFTER the straight block of both elements: thresholds
+// and positions again from the distortions still in registers -- exactly as the hot block formed them --, then every
+// sweep point inside a band is re-solved and the histogram corrected by (+1 exact level, -1 predicted level).
+template <int N>
+__device__ __forceinline__ void hull_counts_fix(uint64_t lanes, const float (&du_hot)[N + 1], const float *tb, float z, float sigma,
+                                                int L, int key0, int nkeys, const unsigned char *perm, const unsigned char *lut,
+                                                const float4 *rec, const float *penl, int *corr, bool all_points) {
+    constexpr int N1 = N + 1;
+    constexpr int PS = (N1 + 3) & ~3;
+    const bool mine = (lanes >> (threadIdx.x & 63u)) & 1ull;
+    float du[N1];
+#pragma unroll
+    for (int n = 0; n < N1; ++n) {                             // opaque copies: nothing below may be hoisted into the hot block
+        float d = du_hot[n];
+        asm volatile("" : "+v"(d));
+        du[n] = d;
+    }
+    float Tn[N];
+    uint32_t apos[N];
+    hull_thresholds<N>(du, Tn);
+    uint32_t fl = (!(hull_max_du<N>(du) < kHullBig) || all_points) ? 0xffffffffu : 0u;   // non-finite costs: every lambda re-solved
+    float G[N];
+    uint32_t near = 0;                                         // bit n: a sweep point lies inside the band of threshold n
+#pragma unroll
+    for (int n = 0; n < N; ++n) {                              // straight code: the twenty table reads overlap
+        float4 nb;
+        apos[n] = hull_position(Tn[n], key0, nkeys, lut, rec, nb);
+        G[n] = hull_band(Tn[n], n, du[n]);
+        const float dist = vmin3abs(__fsub_rn(Tn[n], nb.x), __fsub_rn(Tn[n], nb.y), __fsub_rn(Tn[n], nb.z));
+        near |= (mine && dist <= G[n]) ? (1u << n) : 0u;
+    }
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+        if ((near >> n) & 1u) {
+            // list the sweep points inside this band: they are consecutive and next to T, so walk outwards from its
+            // position (lam_(a-1) < T <= lam_(a); rec[l + 1].x = lam_(l)) -- one or two steps, not a pass over the sweep
+            for (int l = (int)apos[n] - 1; l >= 0 && fabsf(__fsub_rn(rec[l + 1].x, Tn[n])) <= G[n]; --l) fl |= 1u << l;
+            for (int l = (int)apos[n]; l < L && fabsf(__fsub_rn(rec[l + 1].x, Tn[n])) <= G[n]; ++l) fl |= 1u << l;
+        }
+    }
+    fl &= L >= 32 ? 0xffffffffu : ((1u << L) - 1u);
+    if (!mine) fl = 0u;
+    while (fl != 0u) {
+        const int l = __builtin_ctz(fl);
+        fl &= fl - 1u;
+        const int lo_ = perm[l];
+        bool multi;
+        int n_ex = (int)level_of_min<N>(du, penl + lo_ * PS, multi);
+        if (multi) n_ex = N - __builtin_ctz(exact_rank_scan<N>(tb, z, sigma, penl + lo_ * PS) + 1u);
+        int n_pred = 0;                                        // the level the counters assumed: #{ n : a_n > l }
+#pragma unroll
+        for (int n = 0; n < N; ++n) n_pred += apos[n] > (uint32_t)l ? 1 : 0;
+        if (n_ex != n_pred) {
+            atomicAdd(&corr[l * N1 + n_ex], 1);
+            atomicSub(&corr[l * N1 + n_pred], 1);
+        }
+    }
+}
 
 template <int N>
 __global__ void __launch_bounds__(kHullThreads, (VBQ_HULL_WAVES * 256) / kHullThreads)
@@ -510,6 +672,7 @@ k_level_counts_hull(const float *__restrict__ mu, const float *__restrict__ sg, 
     __shared__ unsigned int H[N * LB * KC];                   // [n][a][16 words x 2 halves]
     __shared__ int corr[kMaxLambdaChunk * N1];
     __shared__ unsigned int n_valid;
+    __shared__ unsigned char perm_s[32];
     const int c = blockIdx.y;
     const int L = sw.L;
     for (int i = threadIdx.x; i < T; i += blockDim.x) tb[i] = table[(long)c * T + i];
@@ -517,6 +680,7 @@ k_level_counts_hull(const float *__restrict__ mu, const float *__restrict__ sg, 
         const int l = i / PS, n = i - l * PS;
         penl[i] = n < N1 ? __fmul_rn(lam.lam[l], (float)n) : 0.0f;       // raw lengths, the caller's lambda order
     }
+    if (threadIdx.x < 32) perm_s[threadIdx.x] = sw.perm[threadIdx.x];
     for (int i = threadIdx.x; i < N * LB * KC; i += blockDim.x) H[i] = 0;
     for (int i = threadIdx.x; i < L * N1; i += blockDim.x) corr[i] = 0;
     for (int b = threadIdx.x; b < kHullKeys / 4; b += blockDim.x)   // the bucket table travels in the kernel arguments
@@ -536,6 +700,7 @@ k_level_counts_hull(const float *__restrict__ mu, const float *__restrict__ sg, 
     const unsigned int lane = threadIdx.x & 63u;
     const unsigned int inc = (lane & (unsigned)KC) ? 0x10000u : 1u;
     const unsigned int copy = lane & (unsigned)(KC - 1);
+    const int key0 = sw.key0, nkeys = sw.nkeys;
     unsigned int my_valid = 0;
     float sink = 0.0f;
 
@@ -563,39 +728,11 @@ k_level_counts_hull(const float *__restrict__ mu, const float *__restrict__ sg, 
                 s4[k] = ok ? sg[base + i0 + k] : 1.0f;
             }
         }
-        // ---- phase A: distortion of the NEARER neighbour on every level (du is monotone in |P - z|: one cost per level)
+        // The whole iteration is ONE straight block for both elements (their table reads and LDS round trips overlap); the
+        // only branch, taken by about one wave in ten, goes to the out-of-line fix-up at the end.
         float du[NE][N1];
-        {
-            uint32_t g[NE];
-            double rinv[NE];
 #pragma unroll
-            for (int k = 0; k < NE; ++k) { g[k] = 0; rinv[k] = __ddiv_rn(1.0, (double)s4[k]); }
-#pragma unroll
-            for (int n = 0; n <= N; ++n) {
-                const int off4 = 4 * ((1 << n) - 1);
-                const int top4 = off4;
-#pragma unroll
-                for (int k = 0; k < NE; ++k) {
-                    const float pj = *reinterpret_cast<const float *>(tbb + off4 + g[k]);
-                    const bool below = pj < m4[k];
-                    float dmin;
-                    if (n == 0) {
-                        dmin = __fsub_rn(pj, m4[k]);
-                    } else {
-                        // the visited point is one neighbour of z on this level; the other one sits on z's side of it
-                        // (the same point again at the rim: the deepest level's one-slot-back quirk, quantizer.py:54-57,
-                        // only ever moves the FARTHER candidate, which a minimum does not see)
-                        int o4 = (int)g[k] + (below ? 4 : -4);
-                        o4 = o4 < 0 ? 0 : (o4 > top4 ? top4 : o4);
-                        const float po = *reinterpret_cast<const float *>(tbb + off4 + o4);
-                        dmin = fminf(fabsf(__fsub_rn(pj, m4[k])), fabsf(__fsub_rn(po, m4[k])));
-                    }
-                    const float t = (float)__dmul_rn((double)dmin, rinv[k]);
-                    du[k][n] = __fmul_rn(0.5f, __fmul_rn(t, t));
-                    g[k] = 2 * g[k] + (below ? 4u : 0u);
-                }
-            }
-        }
+        for (int k = 0; k < NE; ++k) hull_du_nearest<N>(tbb, m4[k], s4[k], du[k]);
 #if VBQ_ABL == 3
 #pragma unroll
         for (int k = 0; k < NE; ++k)
@@ -603,110 +740,38 @@ k_level_counts_hull(const float *__restrict__ mu, const float *__restrict__ sg, 
             for (int n = 0; n < N1; ++n) sink += du[k][n];
         continue;
 #endif
-        // ---- thresholds, positions in the sorted sweep, guard bands, counters
-        uint32_t flags[NE];
-        uint32_t apos[NE][N];                                  // a_n, kept for the (rare) corrections
+        uint64_t fix[NE];                                      // lanes whose element k needs the fix-up
 #pragma unroll
         for (int k = 0; k < NE; ++k) {
             const bool valid = i0 + k < n_per_ch;
             my_valid += valid ? 1u : 0u;
-            const unsigned int vinc = valid ? inc : 0u;
-            float Pm[N1];                                      // Pm[j] = min_{i <= n} (du_i - du_j) / (j - i)
+            const unsigned int vinc = valid ? inc : 0u;        // padding lanes add 0: no exec juggling
             float Tn[N];
-            uint64_t near[N];                                  // lanes whose threshold n has a sweep point inside its band
-            float big = du[k][0];
-#pragma unroll
-            for (int j = 1; j + 1 < N1; j += 2) big = vmax3(big, du[k][j], du[k][j + 1]);
-            if ((N1 & 1) == 0) big = vmax(big, du[k][N1 - 1]);
-            uint32_t fl = (!(big < kHullBig) || force_slow) ? 0xffffffffu : 0u;     // non-finite costs: every lambda re-solved
-            uint64_t any_near = 0;
+            hull_thresholds<N>(du[k], Tn);
+            fix[k] = __builtin_amdgcn_ballot_w64(!(hull_max_du<N>(du[k]) < kHullBig)) | (force_slow ? ~0ull : 0ull);
 #pragma unroll
             for (int n = 0; n < N; ++n) {
-#pragma unroll
-                for (int j = n + 1; j < N1; ++j) {
-                    const float r = __fmul_rn(__fsub_rn(du[k][n], du[k][j]), 1.0f / (float)(j - n));
-                    Pm[j] = n == 0 ? r : vmin(Pm[j], r);
-                }
-                float t = Pm[n + 1];
-                {
-                    int j = n + 2;
-#pragma unroll
-                    for (; j + 1 < N1; j += 2) t = vmax3(t, Pm[j], Pm[j + 1]);
-                    if (j < N1) t = vmax(t, Pm[j]);
-                }
-                t = vmin(t, 1.0e38f);                         // inf / NaN (non-finite costs, flagged above) stay inside the tables
-                Tn[n] = t;
 #if VBQ_ABL == 2
-                sink += t; apos[k][n] = 0; near[n] = 0;
+                sink += Tn[n];
                 continue;
 #endif
-                // position: bucket of the threshold's bit pattern (an arithmetic shift keeps T <= 0 negative, so one
-                // median clamps "below the sweep", "above it" and the table range), then the one sweep point that may
-                // share the bucket
-#if VBQ_ABL == 6
-                const float u6 = fmaf(__builtin_amdgcn_logf(vmax(t, 1.0e-37f)), 2.0f, 17.0f);
-                const uint32_t a = (uint32_t)min(max((int)ceilf(u6), 0), L);
-                apos[k][n] = a; near[n] = 0;
-#elif VBQ_ABL == 5
-                const int key = min(max(((int)__float_as_uint(t) >> 16) - sw.key0, 0), sw.nkeys - 1);    // v_med3_i32
-                const uint32_t a = lut[key];
-                apos[k][n] = a; near[n] = 0;
-#else
-                const int key = min(max(((int)__float_as_uint(t) >> 16) - sw.key0, 0), sw.nkeys - 1);    // v_med3_i32
-                const uint32_t cnt = lut[key];
-                const float4 nb = rec[cnt];                    // { lam_(cnt-1), lam_(cnt), lam_(cnt+1) }: one 16-byte read
-                const uint32_t a = cnt + (nb.y < t ? 1u : 0u); // lam_(a-1) < T <= lam_(a)
-                apos[k][n] = a;
-#if VBQ_ABL == 4
-                near[n] = 0;
-#else
-                // band |lambda - T| <= 2^-20 (du_n + |T| (n + 1)): every sweep point outside it is decided by the lines.
-                // T lies between lam_(cnt-1) and lam_(cnt+1), so its distance to the sweep is the smallest of the three.
-                const float G = __fmul_rn(fmaf(fabsf(t), (float)(n + 1), du[k][n]), 9.5367431640625e-07f);
-                const float dist = vmin3abs(__fsub_rn(t, nb.x), __fsub_rn(t, nb.y), __fsub_rn(t, nb.z));
-                near[n] = __builtin_amdgcn_ballot_w64(dist <= G);
-                any_near |= near[n];
-#endif
-#endif
-#if VBQ_ABL == 1
-                sink += (float)a;
-#else
-                atomicAdd(&H[((uint32_t)n * LB + a) * (unsigned)KC + copy], vinc);      // padding lanes add 0: no exec juggling
-#endif
+                float4 nb;
+                const uint32_t a = hull_position(Tn[n], key0, nkeys, lut, rec, nb);
+                const float G = hull_band(Tn[n], n, du[k][n]);
+                const float dist = vmin3abs(__fsub_rn(Tn[n], nb.x), __fsub_rn(Tn[n], nb.y), __fsub_rn(Tn[n], nb.z));
+                fix[k] |= __builtin_amdgcn_ballot_w64(dist <= G);
+                atomicAdd(&H[((uint32_t)n * LB + a) * (unsigned)KC + copy], vinc);
             }
-            if (any_near != 0) {                               // rare: list the sweep points inside the band(s)
-#pragma unroll
-                for (int n = 0; n < N; ++n) {
-                    if (near[n] == 0) continue;
-                    if ((near[n] >> lane) & 1ull) {
-                        const float G = __fmul_rn(fmaf(fabsf(Tn[n]), (float)(n + 1), du[k][n]), 9.5367431640625e-07f);
-                        for (int l = 0; l < L; ++l)
-                            fl |= (fabsf(__fsub_rn(sw.lam[l], Tn[n])) <= G) ? (1u << l) : 0u;
-                    }
-                }
-            }
-            fl &= L >= 32 ? 0xffffffffu : ((1u << L) - 1u);
-            flags[k] = (valid && !never_flag) ? fl : 0u;
+            fix[k] &= __builtin_amdgcn_ballot_w64(valid);      // lane masks are scalars: no branch inside the block
         }
-        // ---- sweep points inside a guard band: literal scan for that (element, lambda), histogram corrected
+        uint64_t any_fix = 0;
 #pragma unroll
-        for (int k = 0; k < NE; ++k) {
-            while (__builtin_amdgcn_ballot_w64(flags[k] != 0u) != 0ull) {
-                if (flags[k] != 0u) {
-                    const int l = __builtin_ctz(flags[k]);
-                    flags[k] &= flags[k] - 1u;
-                    const int lo_ = sw.perm[l];
-                    const uint32_t rk = exact_rank_scan<N>(tb, m4[k], s4[k], penl + lo_ * PS);
-                    const int n_ex = N - __builtin_ctz(rk + 1u);
-                    int n_pred = 0;                            // the level the counters assumed: #{ n : a_n > l }
+        for (int k = 0; k < NE; ++k) any_fix |= fix[k];
+        if (any_fix != 0 && !never_flag) {
 #pragma unroll
-                    for (int n = 0; n < N; ++n) n_pred += apos[k][n] > (uint32_t)l ? 1 : 0;
-                    if (n_ex != n_pred) {
-                        atomicAdd(&corr[l * N1 + n_ex], 1);
-                        atomicSub(&corr[l * N1 + n_pred], 1);
-                    }
-                }
-            }
+            for (int k = 0; k < NE; ++k)
+                if (fix[k] != 0ull)
+                    hull_counts_fix<N>(fix[k], du[k], tb, m4[k], s4[k], L, key0, nkeys, perm_s, lut, rec, penl, corr, force_slow);
         }
     }
     if (VBQ_ABL != 0 && sink == 1.2345e-30f) level_counts[0] = 1;       // keeps the ablated work alive

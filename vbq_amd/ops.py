@@ -351,6 +351,23 @@ def transpose(x: torch.Tensor, out: Optional[torch.Tensor] = None):
     return out
 
 
+def transpose_planes(x: torch.Tensor, out: Optional[torch.Tensor] = None):
+    """vbq_transpose_planes: [batch, rows, cols] -> [batch, cols, rows] for uint16 / float32 / int32 stacks (e.g. plane
+    indices [L, C, B] -> channel-last [L, B, C])."""
+    if not isinstance(x, torch.Tensor) or not x.is_cuda:
+        raise VBQError("transpose_planes: expected a tensor on a ROCm device")
+    if x.dim() != 3 or x.element_size() not in (2, 4):
+        raise ValueError("transpose_planes expects a 3-D tensor of 2- or 4-byte elements")
+    x = x.contiguous()
+    b, r, c = x.shape
+    if out is None:
+        out = torch.empty((b, c, r), dtype=x.dtype, device=x.device)
+    elif tuple(out.shape) != (b, c, r) or out.dtype != x.dtype or not out.is_contiguous() or not out.is_cuda:
+        raise ValueError(f"out must be a contiguous {x.dtype} device tensor of shape {(b, c, r)}")
+    check(_lib.lib().vbq_transpose_planes(_ptr(x), b, r, c, x.element_size(), _ptr(out), _stream(x)), "vbq_transpose_planes")
+    return out
+
+
 def argmax_candidates(P: torch.Tensor, lens: torch.Tensor, mu: torch.Tensor, sigma: torch.Tensor,
                       lambdas: Sequence[float], *, mode="f32", want_j=False):
     """K1c (vbq_argmax_candidates_f32).  P: f32 [M, *shape]; lens: f32 [M, *shape] or [L, M, *shape]."""
