@@ -280,6 +280,20 @@ int vbq_gather_f32(const uint16_t *d_idx, int64_t n_rows, int32_t n_ch, int32_t 
                    float *d_out, int32_t out_layout, void *stream);
 
 /* ----------------------------------------------------------------------------------
+ * Rate-distortion report of a solve: for every lambda l,
+ *     d_out[2l]     += sum_e (z_e - mu_e)^2 / (2 sigma_e^2),   z_e = d_tab_sorted[c(e)][idx[l][e]]   (utils.py:319-320
+ *                      without the sign and the constant: the distortion term the solve minimises)
+ *     d_out[2l + 1] += sum_e d_rate[(l)][c(e)][idx[l][e]]                                          (the bits of
+ *                      quantizer.py:226-228 summed as utils.py:547-549 sums them; skipped when d_rate is NULL)
+ * in f64.  d_tab_sorted is the SORTED table (code_points_by_channel); d_rate is [n_lambda][n_ch][T] when
+ * rate_per_lambda != 0 (entropy_models), else [n_ch][T].  d_out: f64 [n_lambda][2], zero it first.  A report -- the
+ * Lagrangian of BASELINE's R-D gate is d_out[2l] + lambda_l * d_out[2l + 1] -- not an input of any kernel.
+ * ---------------------------------------------------------------------------------- */
+int vbq_rd_sums_u16(const float *d_mu, const float *d_sigma, const uint16_t *d_idx, int64_t n_rows, int32_t n_ch,
+                    int32_t layout, int32_t n_lambda, int32_t N, const float *d_tab_sorted, const float *d_rate,
+                    int32_t rate_per_lambda, double *d_out, void *stream);
+
+/* ----------------------------------------------------------------------------------
  * Layout change between channel-last and channel-major planes: out[c][r] = in[r][c]
  * (f32, LDS-tiled).  Replaces the tf.transpose calls around the solve
  * (quantizer.py:73,163-164,223,228): the hot kernels want [C][B] planes so that a

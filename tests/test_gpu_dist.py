@@ -281,25 +281,53 @@ def test_cabi_communicator_single_rank(tmp_path):
 
 
 @pytest.mark.timeout(600)
-def test_bench_two_ranks_code_path(tmp_path):
-    """bench.py's N > 1 path end to end as the driver launches it (torch.distributed.run, 2 ranks), on one GPU with gloo
-    as the transport (VBQ_BENCH_ONE_DEVICE / VBQ_BENCH_BACKEND: testing switches): one JSON line from rank 0 with the
-    all-reduce report, the packed-counter guard passing, and twice the single-rank work accounted for."""
-    if not torch.cuda.is_available():
-        pytest.fail("gpu-marked test run without a ROCm device")
+def _run_bench_two_ranks(extra, port_off=0):
     import json
     import subprocess
     env = dict(os.environ, VBQ_BENCH_ONE_DEVICE="1", VBQ_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(29700 + os.getpid() % 100), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
-           "--warmup", "1", "--workload", "kodak24_c32", "--no-other-workloads"]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=500, cwd=ROOT)
+           "--master-port", str(29700 + (os.getpid() + port_off) % 100), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
+           "--warmup", "1", "--no-other-workloads"] + extra
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
-    d = json.loads(lines[0])
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_code_path(tmp_path):
+    """bench.py's N > 1 path end to end as the driver launches it (torch.distributed.run, 2 ranks), on one GPU with gloo
+    as the transport (VBQ_BENCH_ONE_DEVICE / VBQ_BENCH_BACKEND: testing switches): one JSON line from rank 0 with the
+    all-reduce report, the packed-counter guard passing, twice the single-rank work accounted for -- and CORRECTNESS
+    evidence: one code book on both ranks, each rank's indices against the oracle, the all-reduced histograms against the
+    sum of the ranks' single-launch histograms, the R-D curve against the oracle's, every rank's own kernel report."""
+    if not torch.cuda.is_available():
+        pytest.fail("gpu-marked test run without a ROCm device")
+    d = _run_bench_two_ranks(["--workload", "kodak24_c32"])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     ar = d["allreduce"]
     assert ar["packed_3x21"] is True and ar["rank_histogram_payload_bytes"] == ((32 * 32 * 2047 + 2) // 3 + 1) * 8
     assert ar["rank_histogram_allreduce_ms_isolated"] > 0 and ar["ms_per_step_without_collectives"] > 0
     assert d["config"]["elements_per_gpu"] == 36864 * 32
+    assert d["pairs_per_step"] == 2 * 36864 * 32 * 32                      # both ranks' pairs, counted once
+    assert d["value"] == pytest.approx(d["pairs_per_step"] / (d["ms_per_step"] * 1e-3), rel=1e-6)
+    par = d["parity"]
+    assert d["parity_vs_oracle_on_sample"] is True and [f["ok"] for f in par["ranks"]] == [True, True]
+    for key in ("pass2_indices_equal_oracle_on_windows", "pass1_level_counts_equal_k1_k2_route_summed_over_ranks",
+                "pass2_rank_counts_equal_single_launch_summed_over_ranks", "counts_total", "length_table_equals_numpy",
+                "models_equal_numpy", "rd_curve_within_1e-5_of_oracle"):
+        assert par[key] is True, key
+    pg = d["per_gpu"]
+    assert [g["rank"] for g in pg] == [0, 1] and all(g["pass2_k1_ms"] > 0 and 0 < g["k1_hbm_frac"] < 1 for g in pg)
+    assert len(d["rd_curve"]["lagrangian_per_latent"]) == 32 and d["rd_curve"]["vs_oracle_on_sample"]["max_rel_diff"] <= 1e-5
+
+
+def test_bench_two_ranks_strong_scaling_splits_one_tensor():
+    """--scaling strong: the rows of ONE tensor are split over the ranks (BASELINE configs[3]'s curve), the pairs of the
+    whole tensor are counted once, and the global histograms hold exactly that tensor."""
+    if not torch.cuda.is_available():
+        pytest.fail("gpu-marked test run without a ROCm device")
+    d = _run_bench_two_ranks(["--workload", "kodak24_c32", "--scaling", "strong"], port_off=37)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong"
+    assert d["config"]["elements_per_gpu"] == 18432 * 32 and d["pairs_per_step"] == 36864 * 32 * 32
+    assert d["parity_vs_oracle_on_sample"] is True and d["parity"]["counts_total"] is True

@@ -15,6 +15,23 @@ void set_error(const char *fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
+int num_cus() {
+    static int cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+        (void)hipGetLastError();
+        dev = 0;
+    }
+    if (cached[dev] <= 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) {
+            (void)hipGetLastError();
+            n = 256;                                             // MI355X; only reached when the query itself fails
+        }
+        cached[dev] = n;
+    }
+    return cached[dev];
+}
 }  // namespace vbq
 
 extern "C" int vbq_abi_version(void) { return VBQ_ABI_VERSION; }

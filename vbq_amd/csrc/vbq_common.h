@@ -10,6 +10,10 @@ namespace vbq {
 
 void set_error(const char *fmt, ...);
 
+// Compute units of the current device (hipDeviceProp_t::multiProcessorCount, cached per device): what the persistent
+// grids are sized by.  256 on MI355X; never hard-coded.
+int num_cus();
+
 #define VBQ_REQUIRE(cond, code, ...)            \
     do {                                        \
         if (!(cond)) {                          \

@@ -336,6 +336,40 @@ k_gather(const uint16_t *__restrict__ idx, long n_rows, int C, int layout, long 
     }
 }
 
+// ---------------------------------------------------------------------------- rate-distortion sums
+// out[l] = { sum_e ((z - mu)^2 / (2 sigma^2)),  sum_e rate[l][c(e)][idx] }  with z = sorted table[c(e)][idx], everything
+// accumulated in f64: the two terms of the Lagrangian the solve minimises, as a report (never used by a kernel).
+__global__ void __launch_bounds__(256)
+k_rd_sums(const float *__restrict__ mu, const float *__restrict__ sg, const uint16_t *__restrict__ idx, long n_rows, int C,
+          int layout, long E, int T, const float *__restrict__ tab_sorted, const float *__restrict__ rate, int rate_per_lambda,
+          double *__restrict__ out) {
+    const int l = blockIdx.y;
+    const uint16_t *src = idx + (long)l * E;
+    const float *rl = rate ? rate + (rate_per_lambda ? (long)l * C * T : 0) : nullptr;
+    double sd = 0.0, sr = 0.0;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (long)gridDim.x * blockDim.x) {
+        const int c = (C == 1) ? 0 : (layout == VBQ_LAYOUT_BC ? (int)(e % C) : (int)(e / n_rows));
+        const int q = min((int)src[e], T - 1);
+        const double d = (double)tab_sorted[(long)c * T + q] - (double)mu[e];
+        const double s = (double)sg[e];
+        sd += d * d / (2.0 * s * s);
+        if (rl) sr += (double)rl[(long)c * T + q];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        sd += __shfl_down(sd, o);
+        sr += __shfl_down(sr, o);
+    }
+    __shared__ double part[2][4];
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { part[0][w] = sd; part[1][w] = sr; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&out[2 * l], part[0][0] + part[0][1] + part[0][2] + part[0][3]);
+        atomicAdd(&out[2 * l + 1], part[1][0] + part[1][1] + part[1][2] + part[1][3]);
+    }
+}
+
 // idx and out in different layouts: 32 x 32 tiles through LDS, both sides coalesced.
 // in_rows x in_cols is the shape of the idx matrix as stored ([C][B] for CB, [B][C] for BC).
 __global__ void __launch_bounds__(256)
@@ -979,6 +1013,26 @@ extern "C" int vbq_gather_f32(const uint16_t *d_idx, int64_t n_rows, int32_t n_c
                        reinterpret_cast<hipStream_t>(stream), d_idx, (long)n_rows, (int)n_ch, (int)layout, (long)E,
                        table_size(N), d_tab, (int)tab_per_lambda, d_out);
     VBQ_CHECK_LAUNCH("gather");
+    return VBQ_OK;
+}
+
+extern "C" int vbq_rd_sums_u16(const float *d_mu, const float *d_sigma, const uint16_t *d_idx, int64_t n_rows, int32_t n_ch,
+                               int32_t layout, int32_t n_lambda, int32_t N, const float *d_tab_sorted, const float *d_rate,
+                               int32_t rate_per_lambda, double *d_out, void *stream) {
+    using namespace vbq;
+    VBQ_REQUIRE(n_rows >= 0 && n_ch >= 1 && n_lambda >= 1 && n_lambda <= 65535 && N >= 0 && N <= 15, VBQ_ERR_INVALID_ARGUMENT,
+                "vbq_rd_sums_u16: bad sizes");
+    VBQ_REQUIRE(layout == VBQ_LAYOUT_BC || layout == VBQ_LAYOUT_CB, VBQ_ERR_INVALID_ARGUMENT, "vbq_rd_sums_u16: unknown layout %d", layout);
+    if (n_rows == 0) return VBQ_OK;
+    VBQ_REQUIRE(d_mu && d_sigma && d_idx && d_tab_sorted && d_out, VBQ_ERR_INVALID_ARGUMENT, "vbq_rd_sums_u16: null pointer argument");
+    const int64_t E = n_rows * (int64_t)n_ch;
+    int64_t gx = (E + 255) / 256;
+    const int64_t cap = 8192 / n_lambda + 1;
+    if (gx > cap) gx = cap;
+    hipLaunchKernelGGL(k_rd_sums, dim3((unsigned)gx, (unsigned)n_lambda), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), d_mu,
+                       d_sigma, d_idx, (long)n_rows, (int)n_ch, (int)layout, (long)E, table_size(N), d_tab_sorted, d_rate,
+                       (int)rate_per_lambda, d_out);
+    VBQ_CHECK_LAUNCH("rd_sums");
     return VBQ_OK;
 }
 

@@ -703,7 +703,7 @@ int launch_notebook_hull10(const float *means, const float *stds, int64_t n, con
     sw.var_hi = fminf(1e38f / sw.b[Lc - 1], 1e30f);
     int64_t gx = ((n + 1) / 2 + 255) / 256;
     constexpr int rounds = 2;                               // grid = this many times the resident workgroups (measured)
-    const int64_t cap = 256 * (ov ? 2 : (Lc <= 32 ? 4 : 3)) * rounds;              // persistent grid: every CU's resident workgroups, two rounds
+    const int64_t cap = (int64_t)num_cus() * (ov ? 2 : (Lc <= 32 ? 4 : 3)) * rounds;              // persistent grid: every CU's resident workgroups, two rounds
     if (gx > cap) gx = cap;
     if (gx < 1) gx = 1;
 #define VBQ_NB_HULL(V, W)                                                                                             \

@@ -416,7 +416,7 @@ int launch_quantize(const float *mu, const float *sg, int64_t n_rows, int32_t n_
                                (!ob || reinterpret_cast<uintptr_t>(ob) % 16 == 0);
             const int64_t nquads = (n_per_ch + 3) / 4;
             int64_t gx = (nquads + 255) / 256;
-            const int64_t cap = (int64_t)256 * 8 / (n_ch < 8 ? n_ch : 8) + 1;   // ~8 resident workgroups per CU in total
+            const int64_t cap = (int64_t)num_cus() * 8 / (n_ch < 8 ? n_ch : 8) + 1;   // ~8 resident workgroups per CU in total
             if (gx > cap) gx = cap;
             if (gx < 1) gx = 1;
             // The fast kernel's tie certificate needs lambda*len to be 0 or comfortably normal.

@@ -1121,7 +1121,7 @@ int launch_quant_fast(const float *mu, const float *sg, int64_t n_per_ch, int64_
     // 3 (NE=4: 53 KB LDS each) / 5 (NE=2) workgroups per CU fit; keep every channel's share balanced.
     // wg_per_cu < 5 leaves LDS and wave slots for a kernel of another stream (K2 overlapping this launch).
     const int per_cu = kFastNE == 4 ? 3 : (wg_per_cu >= 1 && wg_per_cu <= 5 ? wg_per_cu : 5);
-    int64_t cap = (int64_t)256 * per_cu * (wg_per_cu >= 1 ? 1 : 4) / n_ch;
+    int64_t cap = (int64_t)num_cus() * per_cu * (wg_per_cu >= 1 ? 1 : 4) / n_ch;
     if (cap < 1) cap = 1;
     if (gx > cap) {
         // every workgroup walks ceil(iters / gx) chunks: pick the gx in [cap/2, cap] that wastes the
@@ -1133,8 +1133,10 @@ int launch_quant_fast(const float *mu, const float *sg, int64_t n_per_ch, int64_
             if (pad * best < best_pad * g) { best = g; best_pad = pad; }
         }
         gx = best;
-        // count mode: 16-bit partial counters take 16 per iteration at most
-        if (level_counts && (iters + gx - 1) / gx > 4000) gx = (iters + 3999) / 4000;
+        // count mode: a 16-bit partial counter (16 words x 2 halves per (lambda, level)) takes at most 64 / 32 lanes x the waves of
+        // a workgroup x the elements of a lane per iteration
+        constexpr int64_t max_iters = 65000 / ((64 / 32) * (kFastThreads / 64) * kFastNE);
+        if (level_counts && (iters + gx - 1) / gx > max_iters) gx = (iters + max_iters - 1) / max_iters;
     }
     if (gx < 1) gx = 1;
     const dim3 grid((unsigned)gx, (unsigned)n_ch), block(kFastThreads);
@@ -1204,7 +1206,7 @@ int launch_level_counts_hull10(const float *mu, const float *sg, int64_t n_per_c
     const int64_t nquads = (n_per_ch + VBQ_HULL_NE - 1) / VBQ_HULL_NE;
     int64_t gx = (nquads + kHullThreads - 1) / kHullThreads;
     constexpr int rounds = 1;                               // grid = this many times the resident workgroups (measured)
-    int64_t cap = (int64_t)256 * VBQ_HULL_WAVES * rounds * 256 / kHullThreads / n_ch;    // VBQ_HULL_WAVES x 4 waves per CU resident
+    int64_t cap = (int64_t)num_cus() * VBQ_HULL_WAVES * rounds * 256 / kHullThreads / n_ch;    // VBQ_HULL_WAVES x 4 waves per CU resident
     if (cap < 1) cap = 1;
     if (gx > cap) {
         const int64_t iters = gx;
@@ -1239,7 +1241,7 @@ int launch_quant_hull_idx10(const float *mu, const float *sg, int64_t n_per_ch, 
     const int64_t npairs = (n_per_ch + 1) / 2;
     int64_t gx = (npairs + 255) / 256;
     constexpr int rounds = 2;                               // grid = this many times the resident workgroups (measured)
-    int64_t cap = (int64_t)256 * VBQ_K1E_WAVES * rounds / n_ch;          // VBQ_K1E_WAVES workgroups per CU resident
+    int64_t cap = (int64_t)num_cus() * VBQ_K1E_WAVES * rounds / n_ch;          // VBQ_K1E_WAVES workgroups per CU resident
     if (cap < 1) cap = 1;
     if (gx > cap) gx = cap;
     static const int dbg = [] { const char *e = getenv("VBQ_FAST_DEBUG"); return e ? atoi(e) : 0; }();

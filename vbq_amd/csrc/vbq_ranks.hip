@@ -291,9 +291,10 @@ extern "C" int vbq_analogy_ranks_f32(const float *d_emb, int64_t V, int32_t K, c
     // workgroups wastes the least: time ~ ceil(qb * splits / 512) * tiles_per_wg
     const long qb = r.Qp / kBM, nt = r.Vp / kBN;
     long best_s = 1, best_cost = -1;
+    const long slots = (long)num_cus() * VBQ_RANK_WGS;           // workgroups resident at once
     for (long s = 1; s <= nt && s <= 256; ++s) {
         const long tpw = (nt + s - 1) / s;
-        const long cost = ((qb * s + 256 * VBQ_RANK_WGS - 1) / (256 * VBQ_RANK_WGS)) * tpw;
+        const long cost = ((qb * s + slots - 1) / slots) * tpw;
         if (best_cost < 0 || cost < best_cost || (cost == best_cost && tpw >= 8 && s > best_s)) { best_cost = cost; best_s = s; }
     }
     const int tiles_per_wg = (int)((nt + best_s - 1) / best_s);

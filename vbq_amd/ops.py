@@ -351,6 +351,35 @@ def transpose(x: torch.Tensor, out: Optional[torch.Tensor] = None):
     return out
 
 
+def rd_sums(mu: torch.Tensor, sigma: torch.Tensor, idx: torch.Tensor, tab_sorted: torch.Tensor, n_ch: int, *, N: int = 10,
+            layout="bc", rate: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None):
+    """vbq_rd_sums_u16: f64 [L, 2] = per lambda (sum of (z - mu)^2 / (2 sigma^2), sum of rate[idx]) over all elements, z looked
+    up in the SORTED table by rank index.  rate: f32 [C, T] or [L, C, T] (entropy models), or None."""
+    layout = _LAYOUTS[layout]
+    mu = _dev(mu, torch.float32, "mu")
+    sigma = _dev(sigma, torch.float32, "sigma")
+    idx = _dev(idx, torch.uint16, "idx")
+    tab_sorted = _dev(tab_sorted, torch.float32, "tab_sorted")
+    L = idx.shape[0]
+    E = mu.numel()
+    T = table_size(N)
+    if idx[0].numel() != E or sigma.numel() != E or E % n_ch:
+        raise ValueError("mu, sigma and idx[l] must hold the same number of elements, a multiple of n_ch")
+    if tab_sorted.numel() != n_ch * T:
+        raise ValueError(f"tab_sorted has {tab_sorted.numel()} entries, expected {n_ch}*{T}")
+    per_lambda = 0
+    if rate is not None:
+        rate = _dev(rate, torch.float32, "rate")
+        per_lambda = int(rate.dim() == 3)
+        if tuple(rate.shape) != ((L, n_ch, T) if per_lambda else (n_ch, T)):
+            raise ValueError(f"rate shape {tuple(rate.shape)} does not match (L={L}, C={n_ch}, T={T})")
+    if out is None:
+        out = torch.zeros((L, 2), dtype=torch.float64, device=mu.device)
+    check(_lib.lib().vbq_rd_sums_u16(_ptr(mu), _ptr(sigma), _ptr(idx), E // n_ch, n_ch, layout, L, N, _ptr(tab_sorted), _ptr(rate),
+                                     per_lambda, _ptr(out), _stream(mu)), "vbq_rd_sums_u16")
+    return out
+
+
 def transpose_planes(x: torch.Tensor, out: Optional[torch.Tensor] = None):
     """vbq_transpose_planes: [batch, rows, cols] -> [batch, cols, rows] for uint16 / float32 / int32 stacks (e.g. plane
     indices [L, C, B] -> channel-last [L, B, C])."""

@@ -9,10 +9,12 @@
              K1 works on chunk j + 1 (measured: no gain, see __init__)
     models   rank counts -> -log2 frequencies [L, C, T]                                          (:141-146)
 
-Nothing synchronises with the host when the -log2 step can be tabulated (entropy.neg_log2_lut: every row of a
-histogram holds the same number of samples, so -log2(f32(k + n) / f32(total)) is a function of the count k alone
-and the table is built once, on the host, with the reference's own NumPy float32 operations).  When it cannot
-(2^24 samples per row or more, fractional smoothing) the small level table takes one round trip through the host.
+Nothing synchronises with the host.  When the -log2 step can be tabulated (entropy.neg_log2_lut: every row of a
+histogram holds the same number of samples, so -log2(f32(k + n) / f32(total)) is a function of the count k alone and
+the table is built once, on the host, with the reference's own NumPy float32 operations) it is a device lookup.  When
+it cannot (2^24 samples per row or more, fractional smoothing) the small count tables go through a STREAM-ORDERED host
+stage (`HostStage`: asynchronous copy into pinned memory, hipLaunchHostFunc running the reference's NumPy operations,
+asynchronous copy back): still no synchronisation, and the whole step still replays from one HIP graph.
 
 `bench.py` times exactly this object; `ChannelwisePriorCDFQuantizer.build_entropy_models` runs it.
 """
@@ -23,8 +25,73 @@ from typing import Optional, Sequence
 import numpy as np
 import torch
 
+import ctypes as _C
+import glob as _glob
+import os as _os
+
 from . import entropy as _entropy
 from . import ops
+from ._lib import VBQError
+
+_HIP = None
+
+
+def _hip_runtime():
+    """The HIP runtime torch already mapped (for hipLaunchHostFunc, which torch does not expose)."""
+    global _HIP
+    if _HIP is None:
+        cands = _glob.glob(_os.path.join(_os.path.dirname(torch.__file__), "lib", "libamdhip64.so*")) + ["libamdhip64.so"]
+        for c in cands:
+            try:
+                _HIP = _C.CDLL(c)
+                break
+            except OSError:
+                continue
+        if _HIP is None:
+            raise VBQError("libamdhip64.so not found: the stream-ordered host stage needs the HIP runtime")
+        _HIP.hipLaunchHostFunc.restype = _C.c_int
+        _HIP.hipLaunchHostFunc.argtypes = [_C.c_void_p, _C.c_void_p, _C.c_void_p]
+    return _HIP
+
+
+class HostStage:
+    """A host function between two device stages WITHOUT a synchronisation: device tensors -> pinned memory (asynchronous
+    copies), `fn(*host_inputs) -> host_outputs` on the runtime's callback thread (hipLaunchHostFunc, ordered on the stream
+    like a kernel, capturable into a HIP graph as a host node), pinned memory -> device tensors.  Used for the handful of
+    -log2 values per (lambda, channel) that must come from NumPy's own float32 operations (quantizer.py:105-110,141-146)
+    when they cannot be tabulated."""
+    _CB = _C.CFUNCTYPE(None, _C.c_void_p)
+
+    def __init__(self, inputs, outputs, fn):
+        self.inputs, self.outputs, self.fn = list(inputs), list(outputs), fn
+        self.h_in = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in self.inputs]
+        self.h_out = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in self.outputs]
+        self.error = None
+        self._cb = self._CB(self._run)                         # kept alive with the object (a graph may replay it)
+
+    def _run(self, _):
+        try:
+            res = self.fn(*[h.numpy() for h in self.h_in])
+            res = res if isinstance(res, (tuple, list)) else (res,)
+            for h, r in zip(self.h_out, res):
+                np.copyto(h.numpy(), r)
+        except BaseException as e:                             # nothing may propagate into the runtime's thread
+            self.error = e
+
+    def enqueue(self):
+        st = torch.cuda.current_stream(self.inputs[0].device)
+        for h, d in zip(self.h_in, self.inputs):
+            h.copy_(d, non_blocking=True)
+        rc = _hip_runtime().hipLaunchHostFunc(_C.c_void_p(st.cuda_stream), _C.cast(self._cb, _C.c_void_p), None)
+        if rc != 0:
+            raise VBQError(f"hipLaunchHostFunc failed ({rc})")
+        for h, d in zip(self.h_out, self.outputs):
+            d.copy_(h, non_blocking=True)
+
+    def check(self):
+        if self.error is not None:
+            e, self.error = self.error, None
+            raise VBQError(f"host stage failed: {type(e).__name__}: {e}") from e
 
 
 def chunk_bounds(rows: int, n_chunks: int, unit: int = 2048):
@@ -60,9 +127,12 @@ class EntropyModelBuild:
         # The bit-length histogram's small all-reduce sits on the critical path (pass 2 needs its result); on its own
         # communicator it does not queue behind the previous step's large, asynchronous rank-histogram all-reduce.
         self.level_group = level_group if level_group is not None else group
-        self.global_rows = int(global_rows if global_rows is not None else rows)
         # distributed: rows are sharded over the ranks of `group`; the two histograms are summed over them
         self.world = torch.distributed.get_world_size(group) if distributed else 1
+        if distributed and self.world > 1 and global_rows is None:
+            # the tabulated -log2 (and the packed all-reduce) are only valid for the TRUE number of rows behind a histogram row
+            raise ValueError("EntropyModelBuild(distributed=True) needs global_rows = the number of rows summed over all ranks")
+        self.global_rows = int(global_rows if global_rows is not None else rows)
         L, C, N1, T = self.L, self.C, N + 1, self.T
         if counts_dtype is None:       # int32 halves the all-reduce payload; exact while no bin can reach 2^31
             counts_dtype = torch.int32 if self.global_rows < 2 ** 31 else torch.int64
@@ -79,7 +149,22 @@ class EntropyModelBuild:
         self.lut2 = torch.from_numpy(lut2).to(self.dev) if lut2 is not None else None
         self.level_len = torch.empty((L, C, N1), dtype=torch.float32, device=self.dev)
         self.raw_models = torch.empty((L, C, N1), dtype=torch.float32, device=self.dev)
-        self.models = torch.empty((L, C, T), dtype=torch.float32, device=self.dev) if self.lut2 is not None else None
+        # the model table is worth keeping on the device when it is small or can be tabulated; otherwise (C > 1 without a
+        # table: L x C x T values) it is left to the caller (entropy.neg_log2_freq on the counts)
+        self.models = torch.empty((L, C, T), dtype=torch.float32, device=self.dev) \
+            if keep_models and (self.lut2 is not None or L * C * T <= (1 << 22)) else None
+        smooth = add_n_smoothing
+        lv = np.arange(N1, dtype=np.int32).astype(np.float32)
+
+        def lengths_host(level_counts):                       # quantizer.py:105-112 and the "n + overhead" of :171-175
+            raw = _entropy.neg_log2_freq(level_counts, smooth)
+            return (lv + raw).astype(np.float32), raw
+
+        self._len_stage = HostStage([self.level_counts], [self.level_len, self.raw_models], lengths_host) if self.lut1 is None else None
+        self._model_stages = None
+        if self.lut2 is None and self.models is not None:      # quantizer.py:141-146 on the (global) rank counts
+            self._model_stages = [HostStage([c], [self.models], lambda counts: _entropy.neg_log2_freq(counts, smooth))
+                                  for c in self._counts2]
         if n_chunks is None:
             # Measured on the Kodak-24 sweep (profiles/r2_overlap_sweep.txt): K2 one chunk behind K1 on a second stream
             # is SLOWER than running them back to back (1.06 / 1.10 / 1.19 ms per step with 2 / 3 / 6 chunks against
@@ -122,11 +207,8 @@ class EntropyModelBuild:
             ops._lib.check(ops_out(ops._ptr(self.level_counts), 0, self.level_counts.numel(), ops._ptr(self.lut1),
                                    self.lut1.numel(), N1, ops._ptr(self.level_len), ops._ptr(self.raw_models),
                                    ops._stream(self.level_counts)), "vbq_code_lengths_from_counts")
-        else:                          # one round trip of an [L, C, N+1] table through the host
-            raw = _entropy.neg_log2_freq(self.level_counts, self.smooth)
-            lv = np.arange(N1, dtype=np.int32).astype(np.float32)
-            self.raw_models.copy_(torch.from_numpy(raw))
-            self.level_len.copy_(torch.from_numpy((lv + raw).astype(np.float32)))
+        else:                          # the [L, C, N+1] table through a stream-ordered host stage (no synchronisation)
+            self._len_stage.enqueue()
         return self.level_len, self.raw_models
 
     def pass2(self, mu_cb, sg_cb, level_len):
@@ -137,17 +219,19 @@ class EntropyModelBuild:
         self.wait(self._slot)                 # the all-reduce that last used this buffer
         main = torch.cuda.current_stream(self.dev)
         self._models_current = False
-        if self.side is None and self.world == 1 and self.models is not None:
-            # one GPU: K2 owns whole rows of bins, so it assigns them (no zeroing of the 67 MB array) and looks the
-            # code lengths up in the same flush (quantizer.py:141-146)
+        if self.side is None and self.world == 1:
+            # one GPU: K2 owns whole rows of bins, so it assigns them (no zeroing of the 67 MB array) and, when the code
+            # lengths are tabulated, looks them up in the same flush (quantizer.py:141-146)
+            fused = self.lut2 is not None and self.models is not None
             self._t("k1", 0)
             ops.quantize(mu_cb, sg_cb, self.table, self.lambdas, N=self.N, level_len=level_len, layout="cb",
                          out_idx=self.idx, workspace=self.ws)
             self._t("k1", 1)
             self._t("k2", 0)
-            ops.histogram_models(self.idx, self.C, self.counts, N=self.N, lut=self.lut2, models=self.models)
+            ops.histogram_models(self.idx, self.C, self.counts, N=self.N, lut=self.lut2 if fused else None,
+                                 models=self.models if fused else None)
             self._t("k2", 1)
-            self._models_current = True
+            self._models_current = fused
             return self.idx, self.counts
         self.counts.zero_()
         if self.side is None:
@@ -195,14 +279,54 @@ class EntropyModelBuild:
         """quantizer.py:141-146 -> f32 [L, C, T] on the device (table form), or None when the caller must take the
         counts to the host (entropy.neg_log2_freq)."""
         self.wait(self._slot)
-        if self.lut2 is None:
+        if self.models is None:
             return None
         if getattr(self, "_models_current", False):       # K2 wrote them in its flush
+            return self.models
+        if self.lut2 is None:                              # not tabulated: NumPy on the counts, stream-ordered
+            self._model_stages[self._slot].enqueue()
+            self._models_current = True
             return self.models
         ops._lib.check(ops._lib.lib().vbq_code_lengths_from_counts(
             ops._ptr(self.counts), int(self.counts.dtype == torch.int32), self.counts.numel(), ops._ptr(self.lut2),
             self.lut2.numel(), 0, None, ops._ptr(self.models), ops._stream(self.counts)), "vbq_code_lengths_from_counts")
         return self.models
+
+    @property
+    def graph_safe(self) -> bool:
+        """The whole step is stream-ordered work on one stream: it can be captured into a HIP graph."""
+        return self.world == 1 and self.side is None
+
+    @property
+    def length_table_route(self) -> str:
+        return "device (tabulated -log2)" if self.lut1 is not None else \
+            "stream-ordered host stage (NumPy float32 -log2 on [L, C, N+1] counts, hipLaunchHostFunc; no synchronisation)"
+
+    @property
+    def models_route(self) -> str:
+        if self.models is None:
+            return "not in the step (counts stay on the device)"
+        return "device (tabulated -log2)" if self.lut2 is not None else \
+            "stream-ordered host stage (NumPy float32 -log2 on [L, C, T] counts, hipLaunchHostFunc; no synchronisation)"
+
+    def check(self):
+        """Outside the timed region (synchronises): the assumptions no kernel can see.  (1) The tabulated -log2 is only valid
+        when every histogram row holds exactly `global_rows` samples -- a wrong `global_rows` would clamp counts to the
+        table's last entry and give silently wrong models.  (2) The packed 3 x 21-bit all-reduce must not have carried
+        between fields.  (3) A host stage must not have failed on the callback thread."""
+        self.wait()
+        for st in [self._len_stage] + list(self._model_stages or []):
+            if st is not None:
+                torch.cuda.synchronize(self.dev)
+                st.check()
+        if self.collectives or self.world == 1:
+            sums = self.level_counts.sum(dim=-1)
+            if not bool(torch.all(sums == self.global_rows)):
+                raise VBQError(f"bit-length histogram rows hold {int(sums.min())}..{int(sums.max())} samples, not global_rows = "
+                               f"{self.global_rows}: the tabulated code lengths of this build are invalid")
+        for r in self.reducers:
+            if r is not None:
+                r.check()
 
     def run(self, mu_cb, sg_cb, level_len=None, models: bool = True):
         """One whole alternation; everything is enqueued on the current stream (+ the side stream), nothing waits."""
