@@ -196,3 +196,73 @@ def test_config4_shard_1p25e8_64bit_offsets(ops):
     lc = ops.level_counts(mu, sg, tabd, LAM32, N=N, level_len=torch.from_numpy(ll).cuda())
     from vbq_amd import entropy
     assert torch.equal(lc, entropy.level_counts_from_counts(c64, N))
+
+
+def test_config1_kodak24_c256_full_size(ops):
+    """configs[1] at the paper's width, the bench's headline tensor: 36864 x 256 latents (channel-last, as they arrive),
+    per-channel code books, 32-lambda sweep with raw and with corrected lengths.  Oracle on three row windows of all
+    channels and lambdas; on the whole tensor: table[idx] == Z_hat, level(idx) == bits, histogram rows sum to the row
+    count, the two routes to the bit-length histogram agree, rate non-increasing in lambda, and the one-call facade on the
+    channel-last tensors returns the plane kernels' indices transposed."""
+    import vbq_amd
+    from vbq_amd import entropy
+    from scipy.stats import norm
+    B, C = 36864, 256
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev).manual_seed(11)
+    s_c = np.exp(np.random.default_rng(11).uniform(np.log(0.3), np.log(3.0), C))
+    mu = torch.randn((B, C), device=dev, generator=g) * torch.from_numpy(s_c.astype(np.float32)).to(dev)
+    sg = torch.randn((B, C), device=dev, generator=g).mul_(0.7).sub_(2.0).exp_().clamp_(1e-4, 10)
+    xi = np.concatenate([(np.arange(2 ** k) + 0.5) / 2 ** k for k in range(N + 1)])
+    tab = norm.ppf(xi[None, :], scale=s_c[:, None]).astype(np.float32)                  # [C, T]
+    tabd = torch.from_numpy(tab).to(dev)
+    mu_cb, sg_cb = ops.transpose(mu), ops.transpose(sg)
+    rng = np.random.default_rng(12)
+    ll = (np.arange(N + 1, dtype=np.float32)[None, None, :] + rng.uniform(0, 4, (32, C, N + 1)).astype(np.float32)).astype(np.float32)
+    lld = torch.from_numpy(ll).to(dev)
+    wrows = 600
+    for lens, lens_h in ((None, None), (lld, ll)):                                    # K1e (raw sweep) and K1 (corrected)
+        idx = ops.quantize(mu_cb, sg_cb, tabd, LAM32, N=N, layout="cb", level_len=lens)          # [32, C, B]
+        for s in (0, B // 2 - wrows // 2, B - wrows):
+            want = CO.quantize(mu[s:s + wrows].cpu().numpy(), sg[s:s + wrows].cpu().numpy(), tab, LAM32, N=N, level_len=lens_h,
+                               threads=16)                                               # [32, wrows, C]
+            got = idx[:, :, s:s + wrows].permute(0, 2, 1).cpu().numpy()
+            assert np.array_equal(got, want), f"rows {s}..: {int((got != want).sum())} of {got.size} indices differ"
+        cnt = ops.histogram(idx, C, N=N, layout="cb")
+        assert torch.all(cnt.sum(dim=-1) == B)
+        lc = ops.level_counts(mu_cb, sg_cb, tabd, LAM32, N=N, layout="cb", level_len=lens)       # K1t / K1h
+        assert torch.equal(lc, entropy.level_counts_from_counts(cnt, N))
+        if lens is None:
+            bits = (lc.sum(dim=1) * torch.arange(N + 1, device=dev)).sum(dim=1).cpu().numpy()
+            assert np.all(np.diff(bits) <= 0), "total raw rate must not grow with lambda"
+            idx_raw = idx
+    sub = LAM32[5::13]
+    i2, zh, bt = ops.quantize(mu_cb, sg_cb, tabd, sub, N=N, layout="cb", want_zhat=True, want_bits=True)
+    assert torch.equal(i2.view(torch.int16), idx_raw[5::13].view(torch.int16))
+    srt = torch.from_numpy(np.sort(tab, axis=1)).to(dev)
+    lev = torch.from_numpy(LEV.astype(np.float32)).to(dev)
+    for k in range(len(sub)):
+        q = i2[k].to(torch.int64)                                                       # [C, B]
+        assert torch.equal(torch.gather(srt, 1, q), zh[k]) and torch.equal(lev[q], bt[k])
+    fac = vbq_amd.quantize(mu, sg, LAM32, table=tabd)                                 # [32, B, C]
+    assert torch.equal(fac.view(torch.int16), idx_raw.permute(0, 2, 1).contiguous().view(torch.int16))
+
+
+def test_level_counts_single_launch_above_5e8_rows(ops):
+    """The counting kernels keep 16-bit partial counters in LDS and size their grids so that no counter can wrap
+    (vbq_quantize_fast.hip: max_iters in both launchers).  One C = 1 launch over 5.2e8 rows -- four times the largest shard
+    of BASELINE.json -- through K1t (raw lengths), K1h (corrected lengths) and the K1 -> K2 route must agree count for
+    count; one wrapped half-word would show up as a difference of 65536."""
+    from vbq_amd import entropy
+    n = 520_000_000
+    mu, sg = device_inputs(n, seed=9)
+    tabd = torch.from_numpy(gaussian_table(1.2355)).cuda()
+    lam = [0.004, 0.3, 40.0]                                                            # deep, middle and shallow levels busy
+    lc_t = ops.level_counts(mu, sg, tabd, lam, N=N)                                     # K1t
+    idx = ops.quantize(mu, sg, tabd, lam, N=N)                                          # K1 (3 lambdas: the dense kernel)
+    via = entropy.level_counts_from_counts(ops.histogram(idx, 1, N=N), N)
+    assert torch.all(lc_t.sum(dim=-1) == n) and torch.equal(lc_t, via)
+    del idx
+    raw_len = torch.arange(N + 1, dtype=torch.float32, device="cuda").expand(3, 1, -1).contiguous()
+    lc_h = ops.level_counts(mu, sg, tabd, lam, N=N, level_len=raw_len)                  # K1h: same lengths through the dense counting kernel
+    assert torch.equal(lc_h, via)
