@@ -89,6 +89,14 @@ def gaussian_tables(scale):
     return norm.ppf(XI[None, :], scale=np.asarray(scale, dtype=np.float64)[:, None]).astype(np.float32)
 
 
+def make_inputs_with_table(rows, C, seed):
+    """(mu, sigma, table) with the table's second moments summed on the host -- for the developer tools under tools/ (the
+    bench itself takes the moments on the device and all-reduces them: empirical_tables)."""
+    mu, sigma = make_inputs(rows, C, seed)
+    scale = np.sqrt(np.array([np.add.reduce(mu[:, c].astype(np.float64) ** 2) / rows for c in range(C)]))
+    return mu, sigma, gaussian_tables(scale)
+
+
 def empirical_tables(x_dev, rows_local, C, layout):
     """ONE code book for all ranks: sqrt(mean x^2) per channel over every rank's rows (K3 moments on the device, the f64
     sums all-reduced -- ipynb:374 computed globally), then the Gaussian table on the host."""

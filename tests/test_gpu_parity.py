@@ -381,7 +381,10 @@ def test_channel_last_in_planes_out(ops, rows, C):
     for g, w in zip(got, want):
         assert g.shape == (len(lam), C, rows) and np.array_equal(host(g).transpose(0, 2, 1), w)
     with pytest.raises(VBQError, match="fast f32 kernel"):
-        ops.quantize(dev(mu), dev(sg), dev(orc.all_code_points), [0.0, 1.0], N=N, layout="bc->cb")
+        ops.quantize(dev(mu), dev(sg), dev(orc.all_code_points), [0.0, 1.0, 2.0], N=N, layout="bc->cb")
+    # one or two lambdas take the pruned descent (K1p), which only makes the reference's own comparisons: any lambda
+    g0 = ops.quantize(dev(mu), dev(sg), dev(orc.all_code_points), [0.0, 1.0], N=N, layout="bc->cb")
+    assert np.array_equal(host(g0).transpose(0, 2, 1), CO.quantize(mu, sg, orc.all_code_points, [0.0, 1.0], N=N, threads=8))
     with pytest.raises(VBQError, match="fast f32 kernel"):
         ops.quantize(dev(mu), dev(sg), dev(orc.all_code_points), lam, N=N, layout="bc->cb", mode="f64")
 

@@ -14,8 +14,9 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
-from bench import LAMBDAS, N_BITS, make_inputs
+from bench import LAMBDAS, N_BITS, make_inputs_with_table as make_inputs
 from vbq_amd import ops
+
 
 
 def timeit(fn, reps=15):

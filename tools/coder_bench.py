@@ -2,7 +2,7 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from bench import LAMBDAS, make_inputs, N_BITS
+from bench import LAMBDAS, N_BITS, make_inputs_with_table as make_inputs
 from vbq_amd import ops
 from vbq_amd.coder import RansCodec, quantize_frequencies, ideal_bits
 from tools.kbench import timeit

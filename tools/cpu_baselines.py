@@ -2,7 +2,7 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-from bench import LAMBDAS, make_inputs, N_BITS
+from bench import LAMBDAS, N_BITS, make_inputs_with_table as make_inputs
 from oracle import c_oracle as CO, vbq_oracle as O
 th = CO.max_threads()
 print("host threads:", th, "os.cpu_count():", os.cpu_count())

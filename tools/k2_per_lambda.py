@@ -1,7 +1,7 @@
 import sys
 sys.path.insert(0, '/root/repo')
 import numpy as np, torch
-from bench import LAMBDAS, make_inputs, N_BITS
+from bench import LAMBDAS, N_BITS, make_inputs_with_table as make_inputs
 from vbq_amd import ops
 from tools.kbench import timeit
 dev = torch.device("cuda")

@@ -95,14 +95,52 @@ def levels_main(args):
     sys.exit(1 if bad else 0)
 
 
+def small_main(args):
+    """--small: calls with ONE or TWO lambdas (the pruned descent, K1p): every sweep value on its own and in random pairs,
+    raw and corrected lengths (zero and huge overheads included: penalties that never prune / prune at once), all table
+    kinds.  The oracle solves the whole 32-point sweep once per round; the GPU is called per lambda / pair."""
+    dev = torch.device("cuda")
+    rng = np.random.default_rng(4242)
+    total = bad = 0
+    kinds = ["raw", "corr", "dup", "t", "corr", "raw"]
+    for r in range(args.rounds):
+        kind = kinds[r % len(kinds)]
+        tab, mu, sg, ll = case(rng, kind, args.n)
+        if ll is not None and r % 2 == 1:                      # some levels free, some prohibitively long
+            ll = ll.copy()
+            ll[:, :, rng.integers(0, N + 1, 3)] = 0.0
+            ll[:, :, rng.integers(0, N + 1, 2)] = 1.0e6
+        want = CO.quantize(mu, sg, tab, LAM, N=N, level_len=ll, threads=CO.max_threads())[:, :, 0]
+        m, s_, tabd = torch.from_numpy(mu).to(dev), torch.from_numpy(sg).to(dev), torch.from_numpy(tab).to(dev)
+        lld = None if ll is None else torch.from_numpy(ll).to(dev)
+        nb = 0
+        for l in range(len(LAM)):
+            got = ops.quantize(m, s_, tabd, [LAM[l]], N=N, level_len=None if lld is None else lld[l:l + 1].contiguous()).cpu().numpy()
+            nb += int(np.count_nonzero(got[0] != want[l]))
+            total += got.size
+        for _ in range(8):
+            a, b = (int(v) for v in rng.integers(0, len(LAM), 2))
+            lens = None if lld is None else torch.stack([lld[a], lld[b]]).contiguous()
+            got = ops.quantize(m, s_, tabd, [LAM[a], LAM[b]], N=N, level_len=lens).cpu().numpy()
+            nb += int(np.count_nonzero(got[0] != want[a])) + int(np.count_nonzero(got[1] != want[b]))
+            total += got.size
+        bad += nb
+        print(f"round {r} [{kind:4s}] 32 single-lambda calls + 8 pairs over {args.n:.3g} elements: mismatches {nb}", flush=True)
+    print(f"TOTAL {total:.4g} latents compared, {bad} mismatches")
+    sys.exit(1 if bad else 0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=4_000_000)
     ap.add_argument("--rounds", type=int, default=6)
     ap.add_argument("--levels", action="store_true")
+    ap.add_argument("--small", action="store_true")
     args = ap.parse_args()
     if args.levels:
         return levels_main(args)
+    if args.small:
+        return small_main(args)
     dev = torch.device("cuda")
     rng = np.random.default_rng(2024)
     total = bad = 0

@@ -69,6 +69,12 @@ int launch_quant_fast(const float *mu, const float *sg, int64_t n_per_ch, int64_
                       float *out_bits, int64_t E, int vec_ok,
                       unsigned long long *level_counts, int wg_per_cu, hipStream_t st);
 
+// K1p (vbq_quantize_fast.hip): one to four lambdas per call with exact pruning of the descent; indices only.  Returns 1 when the
+// call is not of that kind (the caller takes launch_quant_fast).  Valid for ANY penalties (literal comparisons only).
+template <int N>
+int launch_quant_pruned(const float *mu, const float *sg, int64_t n_per_ch, int64_t ch_stride, int32_t n_ch, const float *table,
+                        const Lambdas32 &lam, const float *len, int32_t L, uint16_t *out_idx, int64_t E, int vec_ok, hipStream_t st);
+
 // K1t (vbq_quantize_fast.hip): first entropy-model pass without a per-lambda loop; N = 10, raw lengths.  Returns 1 when the
 // lambda sweep is not eligible (caller falls back to the dense counting kernel).
 int launch_level_counts_hull10(const float *mu, const float *sg, int64_t n_per_ch, int64_t ch_stride, int32_t n_ch,

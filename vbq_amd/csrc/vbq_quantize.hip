@@ -442,6 +442,15 @@ int launch_quantize(const float *mu, const float *sg, int64_t n_rows, int32_t n_
                 }
             }
             if constexpr (sizeof(PenT) == 4) {
+                // one to four lambdas, indices only: the descent with exact pruning (literal comparisons: any penalties)
+                if (!force_plain_kernel() && !lc_out && oi && !oz && !ob && wg_per_cu == 0) {
+                    const int r = launch_quant_pruned<N>(mu_r, sg_r, n_per_ch, ch_stride, n_ch, table, l32, len_c, Lc, oi, E,
+                                                         vec_ok | (bc_to_cb ? 2 : 0), st);
+                    if (r == VBQ_OK) continue;
+                    if (r < 0) return r;
+                }
+            }
+            if constexpr (sizeof(PenT) == 4) {
                 if (fast_ok) {
                     const int r = launch_quant_fast<N>(mu_r, sg_r, n_per_ch, ch_stride, n_ch, table, l32, len_c, Lc, oi, oz, ob,
                                                        E, vec_ok | (bc_to_cb ? 2 : 0), lc_out, wg_per_cu, st);

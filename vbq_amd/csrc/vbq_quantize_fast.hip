@@ -489,6 +489,7 @@ constexpr int kHullThreads = VBQ_HULL_THREADS;
 #define VBQ_HULL_COPIES 16
 #endif
 constexpr int kHullKeys = 2048;         // 16 octaves of 128 buckets
+constexpr int kFixQueue = 192;          // K1t: deferred fix-ups per workgroup (about ten are expected per 2 300 elements)
 #ifndef VBQ_ABL
 #define VBQ_ABL 0                       // timing ablations of K1t (tools/build_variants.py); wrong results when != 0
 #endif
@@ -512,6 +513,11 @@ __device__ __forceinline__ void hull_du_nearest(const char *tbb, float z, float 
     for (int n = 0; n <= N; ++n) {
         const int off4 = 4 * ((1 << n) - 1);
         const int top4 = off4;
+#if VBQ_ABL == 7 || VBQ_ABL == 8
+        // timing experiment (wrong results): slots that do not depend on the previous level's read -- what a bucket table
+        // on z in front of the descent could buy at most
+        g = ((__float_as_uint(z) >> (20 - n)) & ((1u << n) - 1u)) * 4u;
+#endif
         const float pj = *reinterpret_cast<const float *>(tbb + off4 + g);
         const bool below = pj < z;
         float dmin;
@@ -673,6 +679,7 @@ k_level_counts_hull(const float *__restrict__ mu, const float *__restrict__ sg, 
     __shared__ int corr[kMaxLambdaChunk * N1];
     __shared__ unsigned int n_valid;
     __shared__ unsigned char perm_s[32];
+    __shared__ unsigned int fixq[kFixQueue], fixn;             // elements whose fix-up waits for the end of the loop
     const int c = blockIdx.y;
     const int L = sw.L;
     for (int i = threadIdx.x; i < T; i += blockDim.x) tb[i] = table[(long)c * T + i];
@@ -690,7 +697,7 @@ k_level_counts_hull(const float *__restrict__ mu, const float *__restrict__ sg, 
         auto at = [&](int l) { return l < 0 ? -kHullBig : (l < L ? sw.lam[l < 32 ? l : 31] : kHullBig); };
         rec[i] = make_float4(at(i - 1), at(i), at(i + 1), 0.0f);
     }
-    if (threadIdx.x == 0) n_valid = 0;
+    if (threadIdx.x == 0) { n_valid = 0; fixn = 0; }
     __syncthreads();
 
     const bool force_slow = dbg == 1, never_flag = dbg == 2;
@@ -704,7 +711,9 @@ k_level_counts_hull(const float *__restrict__ mu, const float *__restrict__ sg, 
     unsigned int my_valid = 0;
     float sink = 0.0f;
 
-    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < nquads; q += (long)gridDim.x * blockDim.x) {
+    const long q0 = (long)blockIdx.x * blockDim.x + threadIdx.x, qstep = (long)gridDim.x * blockDim.x;
+    int it = 0;
+    for (long q = q0; q < nquads; q += qstep, ++it) {
         const long i0 = q * NE;
         const bool full = (vec_ok & 1) && (i0 + NE <= n_per_ch);
         float m4[NE], s4[NE];
@@ -733,7 +742,7 @@ k_level_counts_hull(const float *__restrict__ mu, const float *__restrict__ sg, 
         float du[NE][N1];
 #pragma unroll
         for (int k = 0; k < NE; ++k) hull_du_nearest<N>(tbb, m4[k], s4[k], du[k]);
-#if VBQ_ABL == 3
+#if VBQ_ABL == 3 || VBQ_ABL == 7
 #pragma unroll
         for (int k = 0; k < NE; ++k)
 #pragma unroll
@@ -768,10 +777,35 @@ k_level_counts_hull(const float *__restrict__ mu, const float *__restrict__ sg, 
 #pragma unroll
         for (int k = 0; k < NE; ++k) any_fix |= fix[k];
         if (any_fix != 0 && !never_flag) {
+            // About one iteration in ten has such a lane, and the fix-up runs for the whole wave: the element is only NOTED
+            // (iteration, thread, k) in a workgroup queue and repaired after the loop, where all the queued elements of
+            // the workgroup share one pass.  A full queue (adversarial data, the test switch) repairs on the spot.
 #pragma unroll
-            for (int k = 0; k < NE; ++k)
-                if (fix[k] != 0ull)
-                    hull_counts_fix<N>(fix[k], du[k], tb, m4[k], s4[k], L, key0, nkeys, perm_s, lut, rec, penl, corr, force_slow);
+            for (int k = 0; k < NE; ++k) {
+                const bool mine = (fix[k] >> lane) & 1ull;
+                unsigned int slot = kFixQueue;
+                if (mine) slot = atomicAdd(&fixn, 1u);
+                if (mine && slot < (unsigned)kFixQueue) fixq[slot] = ((unsigned int)it << 9) | (threadIdx.x << 1) | (unsigned)k;
+                const uint64_t now = __builtin_amdgcn_ballot_w64(mine && slot >= (unsigned)kFixQueue);
+                if (now != 0ull)
+                    hull_counts_fix<N>(now, du[k], tb, m4[k], s4[k], L, key0, nkeys, perm_s, lut, rec, penl, corr, force_slow);
+            }
+        }
+    }
+    __syncthreads();
+    {   // the queued elements: (mu, sigma) again, the distortions again, then the same fix-up, one element per lane
+        const unsigned int nq = fixn < (unsigned)kFixQueue ? fixn : (unsigned)kFixQueue;
+        for (unsigned int i = threadIdx.x; i < ((nq + 63u) & ~63u); i += blockDim.x) {
+            const bool on = i < nq;
+            const unsigned int e = on ? fixq[i] : 0u;
+            const long qq = q0 + (long)(e >> 9) * qstep + (long)((e >> 1) & 255u) - (long)threadIdx.x;
+            const long el = qq * NE + (long)(e & 1u);
+            const long at = (vec_ok & 2) ? el * C + c : base + el;
+            const float z = on ? mu[at] : 0.0f, sgm = on ? sg[at] : 1.0f;
+            float du[N1];
+            hull_du_nearest<N>(tbb, z, sgm, du);
+            const uint64_t lanes = __builtin_amdgcn_ballot_w64(on);
+            hull_counts_fix<N>(lanes, du, tb, z, sgm, L, key0, nkeys, perm_s, lut, rec, penl, corr, force_slow);
         }
     }
     if (VBQ_ABL != 0 && sink == 1.2345e-30f) level_counts[0] = 1;       // keeps the ablated work alive
@@ -1109,6 +1143,182 @@ k_quant_hull_idx(const float *__restrict__ mu, const float *__restrict__ sg, lon
     }
 }
 
+
+// =====================================================================================================================
+// K1p: the solve for ONE to FOUR lambdas per call -- the literal signature quantize(mu, sigma, lmbda) -- with exact pruning.
+//
+// Per bit level only the NEARER neighbour's distortion is formed (one exact quotient: the cost is monotone in |P - z| and the
+// two sides of a level share their penalty, so min(cost L_n, cost R_n) = fl(min(dL, dR) + pen_n)); per lambda the running
+// minimum S over the levels, the slot that attains it first and a "several levels attain it" mark are kept.  A level deeper
+// than n cannot win or tie once S < min_{m > n} pen_m, because every cost is at least its penalty: the descent stops for
+// the whole wave as soon as that holds for all its lanes and lambdas (at lambda = 1 after four or five of the eleven levels,
+// never at lambda = 2^-8).  Afterwards the two sides of the ONE winning level are compared with the reference's rule (L
+// keeps the level unless fl(dR + pen) < fl(dL + pen)), and the lanes in which several levels attained S -- the
+// reference's candidate order [L_0..L_N, R_1..R_N] decides there -- take the literal scan.  No tie certificate, no
+// precondition on the penalties: every comparison is one the reference makes.
+constexpr int kPrunedMaxL = 2;                       // measured: 1 lambda 15-43 % faster than k_quant_fast, 2 equal, 4 slower (142 against 112 us)
+template <int N, int LL>
+__global__ void __launch_bounds__(256, 4)
+k_quant_pruned(const float *__restrict__ mu, const float *__restrict__ sg, long n_per_ch, long ch_stride, int C,
+               const float *__restrict__ table, Lambdas32 lam, const float *__restrict__ len, uint16_t *__restrict__ out_idx, long E,
+               int vec_ok, int dbg) {
+    constexpr int T = table_size(N);
+    constexpr int N1 = N + 1;
+    constexpr int NE = 2;
+    __shared__ float tb[T + 1];
+    __shared__ __align__(8) float2 ps[LL][N1 + 1];            // { pen[l][n], min_{m >= n} pen[l][m] }; the last row ends the suffix
+    __shared__ float prow[LL][N1 + 1];                         // pen[l][n] again, contiguous: the literal scan's argument
+    const int c = blockIdx.y;
+    for (int i = threadIdx.x; i < T; i += blockDim.x) tb[i] = table[(long)c * T + i];
+    if (threadIdx.x < LL) {
+        const int l = threadIdx.x;
+        float run = 3.0e38f;
+        ps[l][N1] = make_float2(0.0f, run);
+        for (int n = N; n >= 0; --n) {
+            // pen[l][n] = fl32(lambda_l) * len[l][c][n], len = n for the raw lengths (quantizer.py:167-175, utils.py:394-396)
+            const float p = __fmul_rn(lam.lam[l], len ? len[((long)l * C + c) * N1 + n] : (float)n);
+            run = p < run ? p : run;                          // NaN penalties (outside the contract) never prune
+            ps[l][n] = make_float2(p, run);
+            prow[l][n] = p;
+        }
+    }
+    __syncthreads();
+    const bool force_slow = dbg == 1;
+    const long base = (long)c * ch_stride;
+    const long npairs = (n_per_ch + NE - 1) / NE;
+    const char *tbb = reinterpret_cast<const char *>(tb);
+    const unsigned int lane = threadIdx.x & 63u;
+
+    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < npairs; q += (long)gridDim.x * blockDim.x) {
+        const long i0 = q * NE;
+        const bool full = (vec_ok & 1) && (i0 + NE <= n_per_ch);
+        float m4[NE], s4[NE];
+        if (!(vec_ok & 2) && full) {
+            const float2 mv = *reinterpret_cast<const float2 *>(mu + base + i0);
+            const float2 sv = *reinterpret_cast<const float2 *>(sg + base + i0);
+            m4[0] = mv.x; m4[1] = mv.y;
+            s4[0] = sv.x; s4[1] = sv.y;
+        } else {
+#pragma unroll
+            for (int k = 0; k < NE; ++k) {
+                const bool ok = i0 + k < n_per_ch;
+                const long at = (vec_ok & 2) ? (i0 + k) * C + c : base + i0 + k;       // channel-last input: see k_quant_fast
+                m4[k] = ok ? mu[at] : 0.0f;
+                s4[k] = ok ? sg[at] : 1.0f;
+            }
+        }
+        uint32_t g[NE];
+        double rinv[NE];
+        float S[NE][LL];
+        uint32_t win[NE][LL];                                  // byte slot of the visited point (bits 0 .. 12) | level << 16
+        uint64_t multi[NE][LL];                                // lanes in which several levels attain S
+#pragma unroll
+        for (int k = 0; k < NE; ++k) {
+            g[k] = 0;
+            rinv[k] = __ddiv_rn(1.0, (double)s4[k]);
+#pragma unroll
+            for (int l = 0; l < LL; ++l) { S[k][l] = 0.0f; win[k][l] = 0; multi[k][l] = 0; }
+        }
+        // The penalties are read from LDS at every level, through an index the compiler cannot see through: hoisted out of
+        // the element loop (they are loop-invariant) they would occupy 22 registers per lambda and spill.
+        uint32_t opq = 0;
+        asm volatile("" : "+v"(opq));
+        const float *psv = reinterpret_cast<const float *>(&ps[0][0]) + opq;
+#pragma unroll
+        for (int n = 0; n <= N; ++n) {
+            const int off4 = 4 * ((1 << n) - 1);
+            const int top4 = off4;
+            uint64_t active = 0;
+            float pen[LL], stop[LL];                           // this level's penalty; min penalty of every deeper level
+#pragma unroll
+            for (int l = 0; l < LL; ++l) {
+                pen[l] = psv[2 * (l * (N1 + 1) + n)];
+                stop[l] = psv[2 * (l * (N1 + 1) + n + 1) + 1];
+            }
+#pragma unroll
+            for (int k = 0; k < NE; ++k) {
+                const float pj = *reinterpret_cast<const float *>(tbb + off4 + g[k]);
+                const bool below = pj < m4[k];
+                float dmin;
+                if (n == 0) {
+                    dmin = __fsub_rn(pj, m4[k]);
+                } else {
+                    int o4 = (int)g[k] + (below ? 4 : -4);     // the other neighbour sits on z's side of the visited point
+                    o4 = o4 < 0 ? 0 : (o4 > top4 ? top4 : o4);
+                    const float po = *reinterpret_cast<const float *>(tbb + off4 + o4);
+                    dmin = fminf(fabsf(__fsub_rn(pj, m4[k])), fabsf(__fsub_rn(po, m4[k])));
+                }
+                const float t = (float)__dmul_rn((double)dmin, rinv[k]);
+                const float du = __fmul_rn(0.5f, __fmul_rn(t, t));
+                const uint32_t here = g[k] | ((uint32_t)n << 16);
+#pragma unroll
+                for (int l = 0; l < LL; ++l) {
+                    const float cst = __fadd_rn(du, pen[l]);
+                    if (n == 0) {
+                        S[k][l] = cst;
+                        win[k][l] = here;
+                    } else {
+                        const bool lt = cst < S[k][l];
+                        const uint64_t eq = __builtin_amdgcn_ballot_w64(cst == S[k][l]);
+                        multi[k][l] = (multi[k][l] & ~__builtin_amdgcn_ballot_w64(lt)) | eq;
+                        S[k][l] = lt ? cst : S[k][l];
+                        win[k][l] = lt ? here : win[k][l];
+                    }
+                    if (n < N) active |= __builtin_amdgcn_ballot_w64(!(S[k][l] < stop[l]));
+                }
+                g[k] = 2 * g[k] + (below ? 4u : 0u);
+            }
+            if (n < N && active == 0 && n >= 1) break;          // no deeper level can win or tie in this wave
+        }
+        // the winning level's two sides, the reference's rule between them; several levels at S: the literal scan
+        uint32_t rank[LL][NE];
+#pragma unroll
+        for (int k = 0; k < NE; ++k)
+#pragma unroll
+            for (int l = 0; l < LL; ++l) {
+                const uint32_t n = win[k][l] >> 16;
+                const uint32_t gj = win[k][l] & 0xffffu;
+                const uint32_t off4 = 4u * ((1u << n) - 1u), top4 = off4;
+                const float pj = *reinterpret_cast<const float *>(tbb + off4 + gj);
+                const bool below = pj < m4[k];
+                // interval of the level as quantizer.py:75-76 forms it: L = max(G - 1, 0), R = min(G, 2^n - 1), G = slot + [p < z];
+                // on the deepest level the grid has no padding and L stays one slot back above the last point (:54-57)
+                const uint32_t G4 = gj + (below ? 4u : 0u);
+                uint32_t lo4 = G4 >= 4u ? G4 - 4u : 0u;
+                if (n == (uint32_t)N) lo4 = lo4 > top4 - 4u ? top4 - 4u : lo4;
+                const uint32_t hi4 = G4 > top4 ? top4 : G4;
+                const float pen = psv[2 * (l * (N1 + 1) + n)];
+                const float cL = __fadd_rn(dist_cost(*reinterpret_cast<const float *>(tbb + off4 + lo4), m4[k], rinv[k]), pen);
+                const float cR = __fadd_rn(dist_cost(*reinterpret_cast<const float *>(tbb + off4 + hi4), m4[k], rinv[k]), pen);
+                const uint32_t b4 = (n >= 1u && cR < cL) ? hi4 : lo4;             // level 0 has one point
+                rank[l][k] = (((b4 >> 1) + 1u) << ((uint32_t)N - n)) - 1u;         // ((2 pos + 1) << (N - n)) - 1, pos = b4 / 4
+            }
+        uint64_t any_multi = force_slow ? ~0ull : 0ull;
+#pragma unroll
+        for (int k = 0; k < NE; ++k)
+#pragma unroll
+            for (int l = 0; l < LL; ++l) any_multi |= multi[k][l];
+        if (any_multi != 0) {
+#pragma unroll
+            for (int k = 0; k < NE; ++k)
+#pragma unroll
+                for (int l = 0; l < LL; ++l)
+                    if (((multi[k][l] >> lane) & 1ull) || force_slow) rank[l][k] = exact_rank_scan<N>(tb, m4[k], s4[k], prow[l]);
+        }
+#pragma unroll
+        for (int l = 0; l < LL; ++l) {
+            uint16_t *o = out_idx + (long)l * E + base + i0;
+            if (full) {
+                *reinterpret_cast<uint32_t *>(o) = rank[l][0] | (rank[l][1] << 16);
+            } else {
+#pragma unroll
+                for (int k = 0; k < NE; ++k)
+                    if (i0 + k < n_per_ch) o[k] = (uint16_t)rank[l][k];
+            }
+        }
+    }
+}
+
 }  // namespace
 
 template <int N>
@@ -1153,6 +1363,34 @@ int launch_quant_fast(const float *mu, const float *sg, int64_t n_per_ch, int64_
     VBQ_CHECK_LAUNCH("quant_fast");
     return VBQ_OK;
 }
+
+// Host side of K1p: one to four lambdas, indices the only output.  Returns 1 when the call is not its kind.
+template <int N>
+int launch_quant_pruned(const float *mu, const float *sg, int64_t n_per_ch, int64_t ch_stride, int32_t n_ch, const float *table,
+                        const Lambdas32 &lam, const float *len, int32_t L, uint16_t *out_idx, int64_t E, int vec_ok, hipStream_t st) {
+    static const bool off = [] { const char *e = getenv("VBQ_NO_PRUNED"); return e && e[0] == '1'; }();
+    if (off || L < 1 || L > kPrunedMaxL) return 1;
+    const int64_t npairs = (n_per_ch + 1) / 2;
+    int64_t gx = (npairs + 255) / 256;
+    int64_t cap = (int64_t)num_cus() * 4 * 2 / n_ch;            // 4 workgroups per CU resident, two rounds
+    if (cap < 1) cap = 1;
+    if (gx > cap) gx = cap;
+    static const int dbg = [] { const char *e = getenv("VBQ_FAST_DEBUG"); return e ? atoi(e) : 0; }();
+    const dim3 grid((unsigned)gx, (unsigned)n_ch), block(256);
+#define VBQ_PRUNED_CASE(LLv)                                                                                          \
+    case LLv:                                                                                                          \
+        hipLaunchKernelGGL((k_quant_pruned<N, LLv>), grid, block, 0, st, mu, sg, (long)n_per_ch, (long)ch_stride, (int)n_ch, \
+                           table, lam, len, out_idx, (long)E, vec_ok, dbg);                                            \
+        break;
+    switch (L) {
+        VBQ_PRUNED_CASE(1) VBQ_PRUNED_CASE(2) VBQ_PRUNED_CASE(3) VBQ_PRUNED_CASE(4)
+        default: return 1;
+    }
+#undef VBQ_PRUNED_CASE
+    VBQ_CHECK_LAUNCH("quant_pruned");
+    return VBQ_OK;
+}
+
 
 // Sort the sweep by its f32 values and build the bucket table.  false: the sweep is not eligible for the threshold kernels
 // (more than 32 values, a value outside the fast kernels' range, two values in one bucket, more than 16 octaves).
@@ -1259,5 +1497,10 @@ int launch_quant_hull_idx10(const float *mu, const float *sg, int64_t n_per_ch, 
                                        int, unsigned long long *, int, hipStream_t);
 VBQ_FOR_EACH_N(VBQ_INST_FAST)
 #undef VBQ_INST_FAST
+#define VBQ_INST_PRUNED(NN)                                                                                           \
+    template int launch_quant_pruned<NN>(const float *, const float *, int64_t, int64_t, int32_t, const float *,     \
+                                         const Lambdas32 &, const float *, int32_t, uint16_t *, int64_t, int, hipStream_t);
+VBQ_FOR_EACH_N(VBQ_INST_PRUNED)
+#undef VBQ_INST_PRUNED
 
 }  // namespace vbq
