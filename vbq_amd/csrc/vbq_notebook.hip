@@ -375,6 +375,26 @@ __device__ __forceinline__ float nb_min3abs(float a, float b, float c) {
     return r;
 }
 
+// The ten thresholds T_n = max_{j > n} min_{i <= n} (dv_i - dv_j) / (j - i) of an element (see the kernel's header).
+__device__ __forceinline__ void nb_thresholds(const float (&dv)[11], float (&Tn)[10]) {
+    constexpr int N = 10, N1 = 11;
+    float Pm[N1];
+#pragma unroll
+    for (int nn = 0; nn < N; ++nn) {
+#pragma unroll
+        for (int j = nn + 1; j < N1; ++j) {
+            const float r = __fmul_rn(__fsub_rn(dv[nn], dv[j]), 1.0f / (float)(j - nn));
+            Pm[j] = nn == 0 ? r : nb_min(Pm[j], r);
+        }
+        float t = Pm[nn + 1];
+        int j = nn + 2;
+#pragma unroll
+        for (; j + 1 < N1; j += 2) t = nb_max3(t, Pm[j], Pm[j + 1]);
+        if (j < N1) t = nb_max(t, Pm[j]);
+        Tn[nn] = nb_min(t, 1.0e38f);
+    }
+}
+
 template <bool WITH_VAL, int CW>      // CW: words of eight 4-bit fields per column (positions 0 .. L: 5 for L <= 32, 9 for L <= 64)
 __global__ void __launch_bounds__(256, WITH_VAL ? 2 : (CW <= 5 ? 4 : 3))
 k_quant_notebook_hull(const float *__restrict__ means, const float *__restrict__ stds, long n,
@@ -419,6 +439,7 @@ k_quant_notebook_hull(const float *__restrict__ means, const float *__restrict__
     const uint64_t all_l = L >= 64 ? ~0ull : ((1ull << L) - 1ull);
     const unsigned int lane = tid & 63u;
     const long npairs = (n + 1) >> 1;
+    const int key0 = sw.key0, nkeys = sw.nkeys;
     for (long q = (long)blockIdx.x * blockDim.x + tid; q < npairs; q += (long)gridDim.x * blockDim.x) {
         const long i0 = q * 2;
         const bool full = vec_ok && (i0 + 2 <= n);
@@ -485,71 +506,69 @@ k_quant_notebook_hull(const float *__restrict__ means, const float *__restrict__
                 }
             }
         }
-        // ---- thresholds in units of b = w / sigma^2, positions in the sorted sweep, guard bands, the "levels lost" column
-        uint64_t flags[NE];
+        // ---- thresholds in units of b = w / sigma^2, positions in the sorted sweep, guard bands, the "levels lost" column: ONE
+        //      straight block for both elements of the lane (their LDS round trips overlap); a sweep point inside a guard
+        //      band is only NOTED here (lane masks), the list of such points is made after the block, from dv
+        uint64_t fix[NE];
 #pragma unroll
         for (int k = 0; k < NE; ++k) {
-            const bool valid = i0 + k < n;
-            float Pm[N1], Tn[N];
-            uint64_t near[N];
+            float Tn[N];
+            nb_thresholds(dv[k], Tn);
             float big = dv[k][0];
 #pragma unroll
             for (int j = 1; j + 1 < N1; j += 2) big = nb_max3(big, dv[k][j], dv[k][j + 1]);
-            uint64_t fl = (!(big < kNbBig) || slow[k]) ? all_l : 0ull;
-            uint64_t any_near = 0;
+            fix[k] = __builtin_amdgcn_ballot_w64(!(big < kNbBig) || slow[k]);
+            // positions: bucket -> count of sweep points below the bucket -> the one sweep point that may share it
 #pragma unroll
             for (int nn = 0; nn < N; ++nn) {
-#pragma unroll
-                for (int j = nn + 1; j < N1; ++j) {
-                    const float r = __fmul_rn(__fsub_rn(dv[k][nn], dv[k][j]), 1.0f / (float)(j - nn));
-                    Pm[j] = nn == 0 ? r : nb_min(Pm[j], r);
-                }
-                float t = Pm[nn + 1];
-                {
-                    int j = nn + 2;
-#pragma unroll
-                    for (; j + 1 < N1; j += 2) t = nb_max3(t, Pm[j], Pm[j + 1]);
-                    if (j < N1) t = nb_max(t, Pm[j]);
-                }
-                Tn[nn] = nb_min(t, 1.0e38f);
+                const int key = min(max(((int)__float_as_uint(Tn[nn]) >> kNbKeyShift) - key0, 0), nkeys - 1);
+                const uint32_t c0 = lut[key];
+                const float4 nb = rec[c0];
+                const float t = Tn[nn];
+                const uint32_t a = c0 + (nb.y < t ? 1u : 0u);                     // b_(a-1) < T <= b_(a)
+                const float G = __fmul_rn(fmaf(fabsf(t), (float)(nn + 1), dv[k][nn]), 9.5367431640625e-07f);
+                const float dist = nb_min3abs(__fsub_rn(t, nb.x), __fsub_rn(t, nb.y), __fsub_rn(t, nb.z));
+                fix[k] |= __builtin_amdgcn_ballot_w64(dist <= G);
+                atomicAdd(&cnt[((a >> 3) * NE + k) * 256 + tid], 1u << (4u * (a & 7u)));
             }
-            // positions: bucket -> count of sweep points below the bucket -> the one sweep point that may share it.  The ten
-            // table reads go out together, then the ten record reads (two LDS latencies per element instead of twenty).
-            uint32_t c0[N];
+            fix[k] &= __builtin_amdgcn_ballot_w64(i0 + k < n);
+        }
+        // ---- rare (about one iteration in ten): which sweep points to re-solve, thresholds again from dv
+        uint64_t flags[NE] = {0ull, 0ull};
+        if ((fix[0] | fix[1]) != 0ull && !never_flag) {
 #pragma unroll
-            for (int nn = 0; nn < N; ++nn) {
-                const int key = min(max(((int)__float_as_uint(Tn[nn]) >> kNbKeyShift) - sw.key0, 0), sw.nkeys - 1);
-                c0[nn] = lut[key];
-            }
+            for (int k = 0; k < NE; ++k) {
+                if (fix[k] == 0ull) continue;
+                const bool mine = (fix[k] >> lane) & 1ull;
+                float d2[N1], Tn[N];
 #pragma unroll
-            for (int h = 0; h < N; h += 5) {
-                float4 nb[5];
-#pragma unroll
-                for (int i = 0; i < 5; ++i) nb[i] = rec[c0[h + i]];
-#pragma unroll
-                for (int i = 0; i < 5; ++i) {
-                    const int nn = h + i;
-                    const float t = Tn[nn];
-                    const uint32_t a = c0[nn] + (nb[i].y < t ? 1u : 0u);          // b_(a-1) < T <= b_(a)
-                    const float G = __fmul_rn(fmaf(fabsf(t), (float)(nn + 1), dv[k][nn]), 9.5367431640625e-07f);
-                    const float dist = nb_min3abs(__fsub_rn(t, nb[i].x), __fsub_rn(t, nb[i].y), __fsub_rn(t, nb[i].z));
-                    near[nn] = __builtin_amdgcn_ballot_w64(dist <= G);
-                    any_near |= near[nn];
-                    atomicAdd(&cnt[((a >> 3) * NE + k) * 256 + tid], 1u << (4u * (a & 7u)));
+                for (int j = 0; j < N1; ++j) {                 // opaque copies: nothing below may be hoisted into the hot block
+                    float d = dv[k][j];
+                    asm volatile("" : "+v"(d));
+                    d2[j] = d;
                 }
-            }
-            if (any_near != 0) {                               // rare: list the sweep points inside the band(s)
+                nb_thresholds(d2, Tn);
+                float big = d2[0];
+#pragma unroll
+                for (int j = 1; j + 1 < N1; j += 2) big = nb_max3(big, d2[j], d2[j + 1]);
+                uint64_t fl = (!(big < kNbBig) || slow[k]) ? all_l : 0ull;
 #pragma unroll
                 for (int nn = 0; nn < N; ++nn) {
-                    if (near[nn] == 0) continue;
-                    if ((near[nn] >> lane) & 1ull) {
-                        const float G = __fmul_rn(fmaf(fabsf(Tn[nn]), (float)(nn + 1), dv[k][nn]), 9.5367431640625e-07f);
-                        for (int l = 0; l < L; ++l)
-                            fl |= (fabsf(__fsub_rn(sw.b[l], Tn[nn])) <= G) ? (1ull << l) : 0ull;
+                    const int key = min(max(((int)__float_as_uint(Tn[nn]) >> kNbKeyShift) - key0, 0), nkeys - 1);
+                    const uint32_t c0 = lut[key];
+                    const float4 nb = rec[c0];
+                    const uint32_t a = c0 + (nb.y < Tn[nn] ? 1u : 0u);
+                    const float G = __fmul_rn(fmaf(fabsf(Tn[nn]), (float)(nn + 1), d2[nn]), 9.5367431640625e-07f);
+                    const float dist = nb_min3abs(__fsub_rn(Tn[nn], nb.x), __fsub_rn(Tn[nn], nb.y), __fsub_rn(Tn[nn], nb.z));
+                    if (mine && dist <= G) {
+                        // the sweep points inside a band are consecutive and next to T: walk outwards from its position
+                        // (b_(a-1) < T <= b_(a); rec[l + 1].x = b_(l))
+                        for (int l = (int)a - 1; l >= 0 && fabsf(__fsub_rn(rec[l + 1].x, Tn[nn])) <= G; --l) fl |= 1ull << l;
+                        for (int l = (int)a; l < L && fabsf(__fsub_rn(rec[l + 1].x, Tn[nn])) <= G; ++l) fl |= 1ull << l;
                     }
                 }
+                flags[k] = mine ? (fl & all_l) : 0ull;
             }
-            flags[k] = (valid && !never_flag) ? (fl & all_l) : 0ull;
         }
         // ---- emit the sweep: walk the column, level index r = N - level only grows.  The fields of a word sum to at most 10,
         // so one multiplication by 0x11111111 turns them into their eight running sums (no carries between fields); the
@@ -598,7 +617,7 @@ k_quant_notebook_hull(const float *__restrict__ means, const float *__restrict__
                         }
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        *reinterpret_cast<uint32_t *>(oi + (long)row(j) * n) = rank[j][0] | (rank[j][1] << 16);
+                        __builtin_nontemporal_store(rank[j][0] | (rank[j][1] << 16), reinterpret_cast<uint32_t *>(oi + (long)row(j) * n));   // written once, read by a later kernel
                         if (WITH_VAL) *reinterpret_cast<float2 *>(ovp + (long)row(j) * n) = make_float2(val[j][0], val[j][1]);
                     }
                 } else {

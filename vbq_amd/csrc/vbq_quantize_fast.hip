@@ -66,6 +66,15 @@ __device__ __forceinline__ float dist_cost(float P, float mu, double rinv) {
 
 __device__ __forceinline__ float min3f(float a, float b, float c) { return fminf(fminf(a, b), c); }
 
+// Two u16 indices as one 4-byte store.  NT: marked non-temporal -- the indices are written once and read by a later kernel,
+// never by this one.  Measured on the Kodak-24 sweep: K1e (32 stores per lane in one burst) 286 -> 261 us; K1 (one store per
+// lambda-loop pass) unchanged, and K2 right behind it finds the last planes in the memory-side cache: K1 keeps plain stores.
+template <bool NT>
+__device__ __forceinline__ void store_idx2(uint32_t *p, uint32_t v) {
+    if constexpr (NT) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+
 // v_min_f32 / v_max_f32 as they are (IEEE mode: a NaN operand loses).  fminf / fmaxf make the compiler canonicalise
 // operands it cannot prove quiet (a v_max x, x in front of every second min of the threshold recurrences).
 __device__ __forceinline__ float vmin(float a, float b) {
@@ -417,7 +426,7 @@ k_quant_fast(const float *__restrict__ mu, const float *__restrict__ sg, long n_
                         if (out_bits) *reinterpret_cast<float4 *>(out_bits + o) = make_float4(bt[0], bt[1], bt[2], bt[3]);
                     }
                 } else {
-                    *reinterpret_cast<uint32_t *>(out_idx + o) = rank[0] | (rank[1] << 16);
+                    store_idx2<false>(reinterpret_cast<uint32_t *>(out_idx + o), rank[0] | (rank[1] << 16));
                     if (EXTRA) {
                         if (out_zhat) *reinterpret_cast<float2 *>(out_zhat + o) = make_float2(zh[0], zh[1]);
                         if (out_bits) *reinterpret_cast<float2 *>(out_bits + o) = make_float2(bt[0], bt[1]);
@@ -1100,7 +1109,7 @@ k_quant_hull_idx(const float *__restrict__ mu, const float *__restrict__ sg, lon
                         for (int k = 0; k < NE; ++k) rank[j][k] = *reinterpret_cast<const unsigned short *>(rkb + addr(j, k));
 #pragma unroll
                     for (int j = 0; j < 8; ++j)
-                        *reinterpret_cast<uint32_t *>(oi + (long)plane(j) * E) = rank[j][0] | (rank[j][1] << 16);
+                        store_idx2<true>(reinterpret_cast<uint32_t *>(oi + (long)plane(j) * E), rank[j][0] | (rank[j][1] << 16));
                 } else {
                     const int lim = L - wd * 8;
 #pragma unroll
