@@ -95,6 +95,20 @@ def test_build_entropy_models_and_compress(golden):
     # what utils.evaluate_compression_quantizer reads (utils.py:547): total bits per lambda
     bits = [float(np.sum(out["num_bits"][l])) for l in lambs[::7]]
     assert all(np.isfinite(bits))
+    # results are ordinary arrays (a kept one does not hold a page-locked block L times its size), and the staging block is
+    # reused by the next call without touching what was handed out
+    keep = out["Z_hat"][lambs[0]].copy()
+    again = q.compress_latents(means, logvars, lambs[7:9])
+    assert np.array_equal(out["Z_hat"][lambs[0]], keep) and out["Z_hat"][lambs[0]].base is not None
+    assert out["Z_hat"][lambs[0]].base.flags.owndata
+    assert np.array_equal(again["Z_hat"][lambs[7]], out["Z_hat"][lambs[7]])
+    # device-resident outputs: same values, no device-to-host copy
+    dev_out = q.compress_latents(means, logvars, lambs[::7], return_np=False)
+    for lamb in lambs[::7]:
+        for key in ("Z_hat", "raw_num_bits", "num_bits"):
+            t = dev_out[key][lamb]
+            assert isinstance(t, torch.Tensor) and t.is_cuda and tuple(t.shape) == means.shape
+            assert np.array_equal(t.cpu().numpy(), out[key][lamb])
 
 
 def test_utils_solvers_golden(golden):

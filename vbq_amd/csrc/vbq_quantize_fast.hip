@@ -1080,6 +1080,7 @@ k_quant_hull_idx(const float *__restrict__ mu, const float *__restrict__ sg, lon
                 for (int k = 0; k < NE; ++k) cw[wd][k] = atomicExch(&cnt[(wd * NE + k) * 256 + tid], 0u);    // read and clear
             }
         uint16_t *oi = out_idx + base + i0;
+        const uint32_t voff2 = (uint32_t)(2 * (base + i0));    // byte offset inside a plane (planes hold fewer than 2^31 elements)
         if (full) {
             const char *rkb = reinterpret_cast<const char *>(rk);
             uint32_t lbase[NE], run[NE] = {0, 0};
@@ -1089,7 +1090,15 @@ k_quant_hull_idx(const float *__restrict__ mu, const float *__restrict__ sg, lon
 #pragma unroll
             for (int wd = 0; wd < CW - 1; ++wd) {
                 if (wd > nfull) break;
-                const uint2 pw = reinterpret_cast<const uint2 *>(sw.perm)[wd];      // eight plane numbers, one scalar load
+                // eight plane numbers: one uniform LDS read made scalar.  (Read from the kernel arguments, the 32 plane bases are
+                // hoisted out of the element loop into 64 SGPRs, spilled to VGPR lanes and fetched back with two v_readlane
+                // each -- a quarter of the emission's vector instructions.)
+                uint32_t opq = 0;
+                asm volatile("" : "+v"(opq));
+                const uint32_t *pv = reinterpret_cast<const uint32_t *>(perm_s) + 2 * wd + opq;
+                uint2 pw;
+                pw.x = __builtin_amdgcn_readfirstlane(pv[0]);
+                pw.y = __builtin_amdgcn_readfirstlane(pv[1]);
                 uint32_t P[NE];
 #pragma unroll
                 for (int k = 0; k < NE; ++k) {
@@ -1107,9 +1116,13 @@ k_quant_hull_idx(const float *__restrict__ mu, const float *__restrict__ sg, lon
                     for (int j = 0; j < 8; ++j)
 #pragma unroll
                         for (int k = 0; k < NE; ++k) rank[j][k] = *reinterpret_cast<const unsigned short *>(rkb + addr(j, k));
+                    // plane base in scalar registers + one 32-bit lane offset: no 64-bit address arithmetic per store
 #pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        store_idx2<true>(reinterpret_cast<uint32_t *>(oi + (long)plane(j) * E), rank[j][0] | (rank[j][1] << 16));
+                    for (int j = 0; j < 8; ++j) {
+                        const uint16_t *pl = out_idx + (long)plane(j) * E;            // uniform: lives in a scalar register pair
+                        const uint32_t v = rank[j][0] | (rank[j][1] << 16);
+                        asm volatile("global_store_dword %0, %1, %2 nt" : : "v"(voff2), "v"(v), "s"(pl) : "memory");
+                    }
                 } else {
                     const int lim = L - wd * 8;
 #pragma unroll

@@ -347,7 +347,10 @@ class ChannelwisePriorCDFQuantizer:
         return list(sorted(self.entropy_models.keys()))
 
     # ------------------------------------------------------------------ compression (quantizer.py:190-256)
-    def compress_latents(self, posterior_means, posterior_logvars, lambs):
+    def compress_latents(self, posterior_means, posterior_logvars, lambs, return_np=True):
+        """quantizer.py:190-240.  return_np=False keeps the per-lambda results on the device (torch tensors shaped like the
+        latents): no 150 MB device-to-host copy per Kodak image x 32 lambdas, which is what bounds the NumPy form (PCIe).
+        The reference returns NumPy arrays (np.reshape moves to the CPU, :237); that is the default here too."""
         lambs = list(lambs)
         N, C = self.max_bits_per_coord, self.num_channels
         shape = tuple(np.shape(posterior_means))
@@ -374,18 +377,26 @@ class ChannelwisePriorCDFQuantizer:
         num_bits = ops.gather(idx, models_dev, C, N=N, layout="cb", out_layout="bc")                     # :226-228
         out_keys = ("Z_hat", "raw_num_bits", "num_bits_cl", "num_bits")
         output = {key: dict() for key in out_keys}
-        # Device -> host: one pinned host block and ONE asynchronous copy per quantity (the three gathers above are
-        # already queued behind each other, so copy k overlaps nothing it depends on), then per-lambda views.  The
-        # blocks come from torch's caching pinned allocator: warm after the first image, and each returned array
-        # keeps its block alive, so results of earlier calls are never overwritten.
-        host = {}
-        for key, t in (("Z_hat", zhat), ("raw_num_bits", raw_bits), ("num_bits", num_bits)):
-            h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
-            h.copy_(t, non_blocking=True)
-            host[key] = h
-        torch.cuda.current_stream(self.device).synchronize()
         L = len(lambs)
-        arrs = {key: h.numpy().reshape((L,) + shape) for key, h in host.items()}    # [L, B, C] -> L x latent shape (:237)
+        if not return_np:
+            arrs = {"Z_hat": zhat.reshape((L,) + shape), "raw_num_bits": raw_bits.reshape((L,) + shape),
+                    "num_bits": num_bits.reshape((L,) + shape)}
+        else:
+            # Device -> host through ONE persistent pinned staging block per quantity (grown on demand, reused by every
+            # call) and one asynchronous copy each; the caller gets ordinary pageable arrays copied out of it, so a result
+            # kept for later does not pin L times its own size of page-locked memory (an evaluation loop over a whole
+            # data set would otherwise accumulate GBs of it).
+            stage = self._dev_cache.setdefault("_pinned_stage", {})
+            host = {}
+            for key, t in (("Z_hat", zhat), ("raw_num_bits", raw_bits), ("num_bits", num_bits)):
+                h = stage.get(key)
+                if h is None or h.numel() < t.numel() or h.dtype != t.dtype:
+                    h = torch.empty(t.numel(), dtype=t.dtype, pin_memory=True)
+                    stage[key] = h
+                h[:t.numel()].view(t.shape).copy_(t, non_blocking=True)
+                host[key] = h[:t.numel()].view(t.shape)
+            torch.cuda.current_stream(self.device).synchronize()
+            arrs = {key: np.array(h.numpy().reshape((L,) + shape)) for key, h in host.items()}    # [L, B, C] -> L x latent shape (:237)
         for i, lamb in enumerate(lambs):
             output["Z_hat"][lamb] = arrs["Z_hat"][i]
             output["raw_num_bits"][lamb] = arrs["raw_num_bits"][i]
