@@ -19,7 +19,7 @@ src = os.path.join(root, "gpurun_out")
 dst = os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
 
-KERNELS = ("k_level_counts_hull", "k_quant_hull_idx", "k_quant_fast", "k_hist_flat", "k_transpose", "k_prepare_penalties", "k_quant_tiled",
+KERNELS = ("k_level_counts_hull", "k_quant_hull_idx", "k_quant_pruned", "k_quant_fast", "k_transpose_batched", "k_rd_sums", "k_hist_flat", "k_transpose", "k_prepare_penalties", "k_quant_tiled",
            "k_quant_flat", "k_gather", "k_hist_tiled", "k_quant_notebook", "k_lut_lengths", "k_lut_models", "k_np_block_sums")
 
 
