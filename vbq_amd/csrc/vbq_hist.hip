@@ -95,8 +95,14 @@ k_hist_flat(const uint16_t *__restrict__ idx, long n_per_ch, long ch_stride, int
     // the order in which the solve kernel's output is most recent (and still in the memory-side cache) comes first
     const int c = assign == 2 ? C - 1 - (int)blockIdx.z : (int)blockIdx.y;
     const int l = assign == 2 ? (int)blockIdx.y : (int)blockIdx.z;
-    const uint16_t *src = idx + (long)l * E + (long)c * ch_stride;
-    const long noct = vec_ok ? (n_per_ch >> 3) : 0;
+    // The 16-byte loads start at the first 16-byte boundary of this (lambda, channel) row: up to seven leading indices (odd
+    // row counts shift every other row by two bytes) are counted one by one by the row's first workgroup, like the tail.
+    const uint16_t *src0 = idx + (long)l * E + (long)c * ch_stride;
+    const long head_max = (long)(((16u - (unsigned)(reinterpret_cast<uintptr_t>(src0) & 15u)) & 15u) >> 1);
+    const long head = vec_ok ? (head_max < n_per_ch ? head_max : n_per_ch) : 0;
+    const uint16_t *src = src0 + head;
+    const long n_body = n_per_ch - head;
+    const long noct = vec_ok ? (n_body >> 3) : 0;
     const long stride = (long)gridDim.x * blockDim.x;
     long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
     // iterations in which every lane of the wave has two full loads take the aggregated path
@@ -144,8 +150,9 @@ k_hist_flat(const uint16_t *__restrict__ idx, long n_per_ch, long ch_stride, int
             atomicAdd(&h[kHistCopies * bin_slot<N>(w[k] >> 16)], 1u);
         }
     }
-    for (long i = noct * 8 + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n_per_ch; i += stride)
+    for (long i = noct * 8 + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n_body; i += stride)
         atomicAdd(&h[kHistCopies * bin_slot<N>(src[i])], 1u);
+    if (blockIdx.x == 0 && (long)threadIdx.x < head) atomicAdd(&h[kHistCopies * bin_slot<N>(src0[threadIdx.x])], 1u);
     __syncthreads();
     CountT *dst = counts + ((long)l * C + c) * T;
     for (int i = threadIdx.x; i < T; i += blockDim.x) {
@@ -207,8 +214,7 @@ int launch_hist(const uint16_t *idx, int64_t n_rows, int32_t n_ch, int32_t layou
     if (flat) {
         const uint16_t *src = idx + row_begin;
         const int64_t n_per_ch = n_sub;
-        const int vec_ok = (reinterpret_cast<uintptr_t>(src) % 16 == 0) && (n_rows % 8 == 0 || (n_ch == 1 && L == 1)) &&
-                           (E % 8 == 0 || L == 1);
+        const int vec_ok = reinterpret_cast<uintptr_t>(src) % 2 == 0;       // every row finds its own 16-byte boundary (k_hist_flat)
         int64_t gx = (n_per_ch / 8 + kHistThreads - 1) / kHistThreads;
         int64_t cap = (int64_t)2048 / ((int64_t)n_ch * L) + 1;
         if (gx > cap) gx = cap;
@@ -611,7 +617,7 @@ template <int N, typename CountT>
 int launch_hist_assign(const uint16_t *idx, int64_t n_rows, int32_t n_ch, int32_t L, CountT *counts, const float *lut,
                        int64_t lut_n, float *models, hipStream_t st) {
     const int64_t E = n_rows * (int64_t)n_ch;
-    const int vec_ok = (reinterpret_cast<uintptr_t>(idx) % 16 == 0) && (n_rows % 8 == 0 || (n_ch == 1 && L == 1)) && (E % 8 == 0 || L == 1);
+    const int vec_ok = reinterpret_cast<uintptr_t>(idx) % 2 == 0;           // every row finds its own 16-byte boundary (k_hist_flat)
     // last channel first (measured on the Kodak-24 build: 0.7745 against 0.7793 ms per step, three runs each)
     if (n_ch <= 65535)
         hipLaunchKernelGGL((k_hist_flat<N, CountT>), dim3(1u, (unsigned)L, (unsigned)n_ch), dim3(kHistThreads), 0, st, idx, (long)n_rows,

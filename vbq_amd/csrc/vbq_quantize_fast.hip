@@ -1469,13 +1469,13 @@ int launch_level_counts_hull10(const float *mu, const float *sg, int64_t n_per_c
     int64_t cap = (int64_t)num_cus() * VBQ_HULL_WAVES * rounds * 256 / kHullThreads / n_ch;    // VBQ_HULL_WAVES x 4 waves per CU resident
     if (cap < 1) cap = 1;
     if (gx > cap) {
+        // All `cap` workgroups are resident at once and the kernel is latency-bound, so what counts is the number of
+        // iterations the busiest workgroup runs, R = ceil(iters / cap); the fewest workgroups that still need only R keep
+        // the tail balanced.  (Minimising the padding alone once picked 514 workgroups x 38 iterations for 1e7 elements --
+        // half the wave slots empty, 221 us instead of 160.)
         const int64_t iters = gx;
-        int64_t best = cap, best_pad = ((iters + cap - 1) / cap) * cap - iters;
-        for (int64_t g = cap - 1; g >= (cap + 1) / 2 && best_pad > 0; --g) {
-            const int64_t pad = ((iters + g - 1) / g) * g - iters;
-            if (pad * best < best_pad * g) { best = g; best_pad = pad; }
-        }
-        gx = best;
+        const int64_t rounds_needed = (iters + cap - 1) / cap;
+        gx = (iters + rounds_needed - 1) / rounds_needed;
         // 16-bit partial counters: a half takes at most (32 / copies) lanes x 4 waves x NE per iteration
         const int64_t max_iters = 65000 / ((32 / VBQ_HULL_COPIES) * (kHullThreads / 64) * VBQ_HULL_NE);
         if ((iters + gx - 1) / gx > max_iters) gx = (iters + max_iters - 1) / max_iters;
