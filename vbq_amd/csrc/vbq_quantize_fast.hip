@@ -872,7 +872,9 @@ k_level_counts_hull(const float *__restrict__ mu, const float *__restrict__ sg, 
 #ifndef VBQ_K1E_WAVES
 #define VBQ_K1E_WAVES 4
 #endif
-template <int N>
+// LFIX = 32: the sweep has exactly 32 points (four full words of the "levels lost" column): the emission is one straight block
+// -- all 64 rank reads of a lane pair in flight together -- instead of four blocks with a branch and a full LDS latency each.
+template <int N, int LFIX>
 __global__ void __launch_bounds__(256, VBQ_K1E_WAVES)
 k_quant_hull_idx(const float *__restrict__ mu, const float *__restrict__ sg, long n_per_ch, long ch_stride, int C,
                  const float *__restrict__ table, Lambdas32 lam, HullSweep sw, int vec_ok,
@@ -898,7 +900,7 @@ k_quant_hull_idx(const float *__restrict__ mu, const float *__restrict__ sg, lon
     float4 *rec = lds.rec;
     unsigned int *cnt = lds.cnt;
     const int c = blockIdx.y;
-    const int L = sw.L;
+    const int L = LFIX ? LFIX : sw.L;
     const unsigned int tid = threadIdx.x;
     for (int i = tid; i < T; i += blockDim.x) tb[i] = table[(long)c * T + i];
     for (int i = tid; i < L * PS; i += blockDim.x) {
@@ -1087,6 +1089,45 @@ k_quant_hull_idx(const float *__restrict__ mu, const float *__restrict__ sg, lon
 #pragma unroll
             for (int k = 0; k < NE; ++k) lbase[k] = (k * 256 + tid) * 2;           // bits 0 .. 9; the level index goes into bits 10 .. 13
             const int nfull = L >> 3;
+            if constexpr (LFIX == 32) {
+                uint32_t opq = 0;
+                asm volatile("" : "+v"(opq));
+                const uint32_t *pv = reinterpret_cast<const uint32_t *>(perm_s) + opq;
+                uint32_t P[4][NE];
+#pragma unroll
+                for (int wd = 0; wd < 4; ++wd)
+#pragma unroll
+                    for (int k = 0; k < NE; ++k) {
+                        P[wd][k] = (cw[wd][k] + run[k]) * 0x11111111u;
+                        run[k] = P[wd][k] >> 28;
+                    }
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    uint32_t v[16];
+                    uint32_t pw[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) pw[i] = __builtin_amdgcn_readfirstlane(pv[4 * half + i]);
+#pragma unroll
+                    for (int w2 = 0; w2 < 2; ++w2)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const int wd = 2 * half + w2;
+                            uint32_t r2[NE];
+#pragma unroll
+                            for (int k = 0; k < NE; ++k) {
+                                const uint32_t sh = j < 3 ? (P[wd][k] << (10 - 4 * j)) : (P[wd][k] >> (4 * j - 10));
+                                r2[k] = *reinterpret_cast<const unsigned short *>(rkb + ((sh & 0x3c00u) | lbase[k]));
+                            }
+                            v[8 * w2 + j] = r2[0] | (r2[1] << 16);
+                        }
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const uint32_t plane = (pw[i >> 2] >> (8 * (i & 3))) & 0xffu;
+                        const uint16_t *pl = out_idx + (long)plane * E;              // uniform: a scalar register pair
+                        asm volatile("global_store_dword %0, %1, %2 nt" : : "v"(voff2), "v"(v[i]), "s"(pl) : "memory");
+                    }
+                }
+            } else
 #pragma unroll
             for (int wd = 0; wd < CW - 1; ++wd) {
                 if (wd > nfull) break;
@@ -1507,8 +1548,12 @@ int launch_quant_hull_idx10(const float *mu, const float *sg, int64_t n_per_ch, 
     static const int dbg = [] { const char *e = getenv("VBQ_FAST_DEBUG"); return e ? atoi(e) : 0; }();
     Lambdas32 l32;
     for (int i = 0; i < kMaxLambdaChunk; ++i) l32.lam[i] = i < L ? (float)lam[i] : 0.0f;
-    hipLaunchKernelGGL((k_quant_hull_idx<10>), dim3((unsigned)gx, (unsigned)n_ch), dim3(256), 0, st, mu, sg, (long)n_per_ch,
-                       (long)ch_stride, (int)n_ch, table, l32, sw, vec_ok, out_idx, (long)E, dbg);
+    if (L == 32)
+        hipLaunchKernelGGL((k_quant_hull_idx<10, 32>), dim3((unsigned)gx, (unsigned)n_ch), dim3(256), 0, st, mu, sg, (long)n_per_ch,
+                           (long)ch_stride, (int)n_ch, table, l32, sw, vec_ok, out_idx, (long)E, dbg);
+    else
+        hipLaunchKernelGGL((k_quant_hull_idx<10, 0>), dim3((unsigned)gx, (unsigned)n_ch), dim3(256), 0, st, mu, sg, (long)n_per_ch,
+                           (long)ch_stride, (int)n_ch, table, l32, sw, vec_ok, out_idx, (long)E, dbg);
     VBQ_CHECK_LAUNCH("quant_hull_idx");
     return VBQ_OK;
 }

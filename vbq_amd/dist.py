@@ -139,6 +139,9 @@ class CountsAllReduce:
     reaches 2^21 / world, the flag travels in a spare word of the same all-reduce (so every rank sees the same
     answer), and `check()` -- one device-to-host read, call it outside the timed loop, or `wait(check=True)` --
     raises VBQError when any rank flagged: the sums of that step cannot be trusted then (use packed=False).
+    The guard is CONSERVATIVE: a rank that holds more than 1 / world of a bin flags although the global sum may still be
+    below 2^21 (unbalanced shards); the error then costs a retry with packed=False, never a wrong count.
+    `EntropyModelBuild.check()` calls it after a build.
     """
 
     def __init__(self, numel: int, device, max_global_count: int, group=None, packed: Optional[bool] = None):
