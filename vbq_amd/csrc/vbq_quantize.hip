@@ -409,11 +409,19 @@ int launch_quantize(const float *mu, const float *sg, int64_t n_rows, int32_t n_
         if (flat) {
             const int64_t n_per_ch = n_sub;                    // per channel (n_ch == 1: the whole range)
             const int64_t ch_stride = n_rows;
+            // 16-byte accesses of the literal kernel (4 elements per thread) want 16-byte aligned rows and planes
             const int vec_ok = ((n_rows % 4 == 0) || n_ch == 1) &&
                                ((reinterpret_cast<uintptr_t>(mu_r) | reinterpret_cast<uintptr_t>(sg_r)) % 16 == 0) &&
                                (reinterpret_cast<uintptr_t>(oi) % 8 == 0) && (E % 4 == 0 || L == 1) &&
                                (!oz || reinterpret_cast<uintptr_t>(oz) % 16 == 0) &&
                                (!ob || reinterpret_cast<uintptr_t>(ob) % 16 == 0);
+            // The fast kernels move PAIRS: 8-byte loads, 4-byte index stores, 8-byte Z_hat / length stores.  Compute queues run
+            // with unaligned access enabled (ROCm's SH_MEM_CONFIG alignment mode; LLVM's amdhsa target assumes it), so element
+            // alignment is all they need: odd row counts shift every other plane by half a pair and still take the paired
+            // path (1.3e7 + 1 elements: K1e 52 -> 25 us per 1e6, tools/k1t_sizes.py).
+            const int vec2_ok = ((reinterpret_cast<uintptr_t>(mu_r) | reinterpret_cast<uintptr_t>(sg_r)) % 4 == 0) &&
+                                (reinterpret_cast<uintptr_t>(oi) % 2 == 0) && (!oz || reinterpret_cast<uintptr_t>(oz) % 4 == 0) &&
+                                (!ob || reinterpret_cast<uintptr_t>(ob) % 4 == 0);
             const int64_t nquads = (n_per_ch + 3) / 4;
             int64_t gx = (nquads + 255) / 256;
             const int64_t cap = (int64_t)num_cus() * 8 / (n_ch < 8 ? n_ch : 8) + 1;   // ~8 resident workgroups per CU in total
@@ -427,7 +435,7 @@ int launch_quantize(const float *mu, const float *sg, int64_t n_rows, int32_t n_
                 // first entropy-model pass (raw lengths, levels only): thresholds instead of a per-lambda loop
                 if (fast_ok && lc_out && !len_c) {
                     const int r = launch_level_counts_hull10(mu_r, sg_r, n_per_ch, ch_stride, n_ch, table, lc.lam, Lc,
-                                                             vec_ok | (bc_to_cb ? 2 : 0), lc_out, st);
+                                                             vec2_ok | (bc_to_cb ? 2 : 0), lc_out, st);
                     if (r == VBQ_OK) continue;
                     if (r < 0) return r;
                 }
@@ -436,7 +444,7 @@ int launch_quantize(const float *mu, const float *sg, int64_t n_rows, int32_t n_
                 // a raw-length sweep with indices as the only output: thresholds, then a walk down the staircase
                 if (fast_ok && !lc_out && !len_c && oi && !oz && !ob) {
                     const int r = launch_quant_hull_idx10(mu_r, sg_r, n_per_ch, ch_stride, n_ch, table, lc.lam, Lc,
-                                                          vec_ok | (bc_to_cb ? 2 : 0), oi, E, st);
+                                                          vec2_ok | (bc_to_cb ? 2 : 0), oi, E, st);
                     if (r == VBQ_OK) continue;
                     if (r < 0) return r;
                 }
@@ -445,7 +453,7 @@ int launch_quantize(const float *mu, const float *sg, int64_t n_rows, int32_t n_
                 // one to four lambdas, indices only: the descent with exact pruning (literal comparisons: any penalties)
                 if (!force_plain_kernel() && !lc_out && oi && !oz && !ob && wg_per_cu == 0) {
                     const int r = launch_quant_pruned<N>(mu_r, sg_r, n_per_ch, ch_stride, n_ch, table, l32, len_c, Lc, oi, E,
-                                                         vec_ok | (bc_to_cb ? 2 : 0), st);
+                                                         vec2_ok | (bc_to_cb ? 2 : 0), st);
                     if (r == VBQ_OK) continue;
                     if (r < 0) return r;
                 }
@@ -453,7 +461,7 @@ int launch_quantize(const float *mu, const float *sg, int64_t n_rows, int32_t n_
             if constexpr (sizeof(PenT) == 4) {
                 if (fast_ok) {
                     const int r = launch_quant_fast<N>(mu_r, sg_r, n_per_ch, ch_stride, n_ch, table, l32, len_c, Lc, oi, oz, ob,
-                                                       E, vec_ok | (bc_to_cb ? 2 : 0), lc_out, wg_per_cu, st);
+                                                       E, vec2_ok | (bc_to_cb ? 2 : 0), lc_out, wg_per_cu, st);
                     if (r != VBQ_OK) return r;
                     continue;
                 }
