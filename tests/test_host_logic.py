@@ -134,3 +134,49 @@ def test_f64_reciprocal_division_identity():
         q = a / b
         q2 = (a.astype(np.float64) * (1.0 / b.astype(np.float64))).astype(np.float32)
         assert np.array_equal(q, q2)
+
+
+def test_bench_inputs_and_rd_helpers():
+    """bench.py's host helpers: ranks draw different rows of ONE population (same per-channel spreads, so that one code book
+    for all ranks is meaningful), the Gaussian tables are level-major and ascending per level, and the oracle-side R-D
+    curve equals oracle.lagrangian summed the other way."""
+    import bench
+    from oracle import vbq_oracle as O
+    mu0, sg0 = bench.make_inputs(400, 5, seed=1000)
+    mu1, sg1 = bench.make_inputs(400, 5, seed=1001)
+    assert mu0.shape == (400, 5) and mu0.dtype == np.float32 and not np.array_equal(mu0, mu1)
+    s0, s1 = mu0.std(axis=0), mu1.std(axis=0)
+    assert np.all(np.abs(s0 / s1 - 1) < 0.25) and (s0.max() / s0.min() > 1.5)          # same spreads per channel, different across channels
+    assert sg0.min() >= 1e-4 and sg0.max() <= 10
+    tab = bench.gaussian_tables(np.sqrt(np.mean(mu0.astype(np.float64) ** 2, axis=0)))
+    assert tab.shape == (5, bench.T) and tab.dtype == np.float32
+    for n in range(bench.N_BITS + 1):
+        lv = tab[:, 2 ** n - 1:2 ** (n + 1) - 1]
+        assert np.all(np.diff(lv, axis=1) > 0)
+    lam = [0.05, 1.0, 20.0]
+    rng = np.random.default_rng(3)
+    idx = rng.integers(0, bench.T, (3, 400, 5))
+    models = np.abs(rng.normal(5, 2, (3, 5, bench.T))).astype(np.float32)
+    got = bench.rd_curve_oracle(mu0, sg0, idx, tab, models, lam)
+    srt = np.sort(tab, axis=1)
+    ch = np.arange(5)[None, :]
+    for l in range(3):
+        z = srt[ch, idx[l]]
+        bits = models[l][ch, idx[l]]
+        want = O.lagrangian(mu0, sg0, z, bits, lam[l]) / mu0.size
+        assert abs(got["lagrangian"][l] - want) <= 1e-12 * abs(want)
+    assert bench.sweep_name(bench.LAMBDAS).startswith("2**linspace(-8,7.5") and "post_process" in bench.sweep_name(bench.LAMBDAS_16)
+
+
+def test_quantize_facade_table_cache_keys():
+    """The facade checks a table once per OBJECT: the key changes with the object, its storage and (tensors) its version
+    counter, so a new or edited table is checked again."""
+    import torch
+    from vbq_amd import api
+    a = np.zeros((2, 7), np.float32)
+    b = a.copy()
+    assert api._table_key(a) != api._table_key(b) and api._table_key(a) == api._table_key(a)
+    t = torch.zeros((2, 7))
+    k0 = api._table_key(t)
+    t[0, 0] = 1.0
+    assert api._table_key(t) != k0
