@@ -71,10 +71,20 @@ def main():
             means, stds = means[:-1], stds[:-1]
         idx, val = ops.quantize_notebook(torch.from_numpy(means).to(dev), torch.from_numpy(stds).to(dev), torch.from_numpy(pts).to(dev), betas, N=N)
         idx, val = idx.cpu().numpy(), val.cpu().numpy()
+        md, sd, pd_ = torch.from_numpy(means).to(dev), torch.from_numpy(stds).to(dev), torch.from_numpy(pts).to(dev)
         for i, b in enumerate(betas):
             v, slot = CO.compress_coordinates(means, stds, b, pts, lens, threads=CO.max_threads())
             nb = int(np.count_nonzero(idx[i].astype(np.int64) != rank_of_slot[slot])) + int(np.count_nonzero(val[i] != v))
             tot += means.size; bad += nb
+            if i % 4 == 0:
+                # the same beta on its own and paired with the next one: the calls of test_beta (ipynb:466) take the pruned
+                # descent (K1np), with and without the values
+                pair = [b] if i % 8 == 0 else [b, betas[(i + 1) % len(betas)]]
+                i1, v1 = ops.quantize_notebook(md, sd, pd_, pair, N=N, want_values=(i % 3 != 0))
+                nb = int(np.count_nonzero(i1[0].cpu().numpy().astype(np.int64) != rank_of_slot[slot]))
+                if v1 is not None:
+                    nb += int(np.count_nonzero(v1[0].cpu().numpy() != v))
+                tot += means.size; bad += nb
         print(f"round {rnd}: scale {scale:.3g}, {len(betas)} betas{' (on thresholds)' if kind == 3 else ''}, "
               f"{len(betas) * means.size:.3g} latents, mismatches so far {bad}", flush=True)
     print("TOTAL", tot, "mismatches", bad)

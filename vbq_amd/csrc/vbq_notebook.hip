@@ -32,6 +32,12 @@ __device__ __forceinline__ double sq_err(double c, double z) {
     return __dmul_rn(d, d);
 }
 
+// v_min_f64 as it is (fmin makes the compiler canonicalise both operands: two v_max_f64 x, x per call)
+__device__ __forceinline__ double nb_min64(double a, double b) {
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 template <int N>
 __device__ __forceinline__ void search_and_score_d(const double *tb, double z, ElemD<N> &e) {
     uint32_t g = 0;
@@ -318,6 +324,139 @@ k_quant_notebook_fast(const float *__restrict__ means, const float *__restrict__
 
 
 // ------------------------------------------------------------------------------------------
+// K1np: compress_coordinates for ONE or TWO betas per call -- how the notebook itself calls it (test_beta, ipynb:466, in a
+// loop over 50 betas, ipynb:1103) -- with exact pruning of the descent.
+//
+// Per bit level only the nearer neighbour's squared error is formed (monotone rounding: it is the smaller one) and
+// cost_n = fl64(err_n + w n) (the product is exact: w is an f32 number).  The notebook takes the FIRST minimum in level-major
+// order, so a deeper level wins only with a strictly smaller cost: the running minimum with a strict compare IS the scan
+// across levels, no tie rule is left over.  Every cost is at least its penalty w n, so the descent stops for the whole wave
+// once best <= w (n + 1) holds in all its lanes.  The two sides of the one winning level are compared at the end exactly as
+// the scan compares them (L first; R only if strictly smaller).  Only comparisons the reference makes: no certificate, no
+// fall-back.
+template <int N, int LL, bool WITH_VAL>
+__global__ void __launch_bounds__(256)
+k_quant_notebook_pruned(const float *__restrict__ means, const float *__restrict__ stds, long n,
+                        const double *__restrict__ codebook, BetaChunk bc, uint16_t *__restrict__ out_idx,
+                        float *__restrict__ out_val, int vec_ok) {
+    constexpr int T = table_size(N);
+    constexpr int NE = 2;
+    __shared__ double tb[T + 1];
+    for (int i = threadIdx.x; i < T; i += blockDim.x) tb[i] = codebook[i];
+    __syncthreads();
+    float tb2[LL];
+#pragma unroll
+    for (int l = 0; l < LL; ++l) tb2[l] = (float)(2.0 * bc.beta[l]);
+    const char *tbb = reinterpret_cast<const char *>(tb);
+    const long npairs = (n + 1) >> 1;
+    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < npairs; q += (long)gridDim.x * blockDim.x) {
+        const long i0 = q * 2;
+        const bool full = vec_ok && (i0 + 2 <= n);
+        float m2[NE], s2[NE];
+        if (full) {
+            const float2 mv = *reinterpret_cast<const float2 *>(means + i0);
+            const float2 sv = *reinterpret_cast<const float2 *>(stds + i0);
+            m2[0] = mv.x; m2[1] = mv.y; s2[0] = sv.x; s2[1] = sv.y;
+        } else {
+#pragma unroll
+            for (int k = 0; k < NE; ++k) {
+                const bool ok = i0 + k < n;
+                m2[k] = ok ? means[i0 + k] : 0.0f;
+                s2[k] = ok ? stds[i0 + k] : 1.0f;
+            }
+        }
+        double z[NE], w[NE][LL], best[NE][LL];
+        uint32_t g[NE], win[NE][LL];                           // byte slot of the visited point (bits 0 .. 13) | level << 16
+#pragma unroll
+        for (int k = 0; k < NE; ++k) {
+            z[k] = (double)m2[k];
+            g[k] = 0;
+            const float var = __fmul_rn(s2[k], s2[k]);
+#pragma unroll
+            for (int l = 0; l < LL; ++l) {
+                w[k][l] = (double)__fmul_rn(tb2[l], var);      // fl32(fl32(2 beta) * fl32(sigma^2)), ipynb:438 under NumPy 1.17
+                best[k][l] = 0.0;
+                win[k][l] = 0;
+            }
+        }
+        bool done = false;                                     // wave-uniform; a flag instead of a break keeps the loop unrollable
+#pragma unroll
+        for (int lv = 0; lv <= N; ++lv) {
+            if (done) continue;
+            const int off8 = 8 * ((1 << lv) - 1);
+            const int top8 = off8;
+            uint64_t active = 0;
+#pragma unroll
+            for (int k = 0; k < NE; ++k) {
+                const double pj = *reinterpret_cast<const double *>(tbb + off8 + g[k]);
+                const double d1 = __dsub_rn(pj, z[k]);
+                const bool below = pj < z[k];
+                double err;
+                if (lv == 0) {
+                    err = __dmul_rn(d1, d1);
+                } else {
+                    int o8 = (int)g[k] + (below ? 8 : -8);     // the other neighbour sits on z's side of the visited point
+                    o8 = o8 < 0 ? 0 : (o8 > top8 ? top8 : o8);
+                    const double po = *reinterpret_cast<const double *>(tbb + off8 + o8);
+                    const double d2 = __dsub_rn(po, z[k]);
+                    const double dn = nb_min64(fabs(d1), fabs(d2));
+                    err = __dmul_rn(dn, dn);
+                }
+                const uint32_t here = g[k] | ((uint32_t)lv << 16);
+#pragma unroll
+                for (int l = 0; l < LL; ++l) {
+                    const double cst = lv == 0 ? err : __fma_rn(w[k][l], (double)lv, err);
+                    const bool lt = lv == 0 || cst < best[k][l];
+                    best[k][l] = lt ? cst : best[k][l];
+                    win[k][l] = lt ? here : win[k][l];
+                    if (lv < N) active |= __builtin_amdgcn_ballot_w64(!(best[k][l] <= __dmul_rn(w[k][l], (double)(lv + 1))));
+                }
+                g[k] = 2 * g[k] + (below ? 8u : 0u);
+            }
+            if (lv < N && active == 0) done = true;            // no deeper level can cost less in this wave
+        }
+        uint32_t rank[LL][NE];
+        float val[LL][NE];
+#pragma unroll
+        for (int k = 0; k < NE; ++k)
+#pragma unroll
+            for (int l = 0; l < LL; ++l) {
+                const uint32_t lv = win[k][l] >> 16;
+                const uint32_t gj = win[k][l] & 0xffffu;
+                const uint32_t off8 = 8u * ((1u << lv) - 1u), top8 = off8;
+                const double pj = *reinterpret_cast<const double *>(tbb + off8 + gj);
+                const bool below = pj < z[k];
+                int o8 = (int)gj + (below ? 8 : -8);
+                o8 = o8 < 0 ? 0 : (o8 > (int)top8 ? (int)top8 : o8);
+                const double po = *reinterpret_cast<const double *>(tbb + off8 + o8);
+                const double pen = __dmul_rn(w[k][l], (double)lv);
+                const double cj = __dadd_rn(sq_err(pj, z[k]), pen), co = __dadd_rn(sq_err(po, z[k]), pen);
+                // L is the visited point when it lies below z; the scan takes L first and R only if strictly smaller
+                const bool take_j = below ? !(co < cj) : (cj < co);
+                const uint32_t b8 = (lv == 0u || take_j) ? gj : (uint32_t)o8;
+                rank[l][k] = (((b8 >> 2) + 1u) << ((uint32_t)N - lv)) - 1u;          // ((2 pos + 1) << (N - lv)) - 1, pos = b8 / 8
+                if (WITH_VAL) val[l][k] = (float)((lv == 0u || take_j) ? pj : po);
+            }
+#pragma unroll
+        for (int l = 0; l < LL; ++l) {
+            const long o = (long)l * n + i0;
+            if (full) {
+                *reinterpret_cast<uint32_t *>(out_idx + o) = rank[l][0] | (rank[l][1] << 16);
+                if (WITH_VAL) *reinterpret_cast<float2 *>(out_val + o) = make_float2(val[l][0], val[l][1]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < NE; ++k)
+                    if (i0 + k < n) {
+                        out_idx[o + k] = (uint16_t)rank[l][k];
+                        if (WITH_VAL) out_val[o + k] = val[l][k];
+                    }
+            }
+        }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------
 // K1nt: the beta sweep without a per-beta argmin (N = 10).
 //
 // The notebook's cost of bit level n is a LINE in the penalty weight, err_n + w * n with w = fl32(fl32(2 beta) * fl32(sigma^2))
@@ -489,14 +628,16 @@ k_quant_notebook_hull(const float *__restrict__ means, const float *__restrict__
                         jo = jo < 0 ? 0 : (jo > m - 1 ? m - 1 : jo);
                         const double po = tb[off + jo];
                         const double ej = sq_err(pj, z), eo = sq_err(po, z);
-                        const double errL = below ? ej : eo, errR = below ? eo : ej;
-                        const bool r_better = errR < errL;
-                        du = r_better ? errR : errL;
+                        // errL = below ? ej : eo, errR = below ? eo : ej (the visited point is L when it lies below z), without the
+                        // four selects: the better side's error is the minimum, and "R strictly better" is a sign of ej - eo
+                        const double diff = __dsub_rn(ej, eo);             // = errL - errR when below, errR - errL otherwise (exact negation)
+                        const bool r_better = below ? diff > 0.0 : diff < 0.0;
+                        du = nb_min64(ej, eo);
                         pos = (r_better != below) ? j : (uint32_t)jo;      // L is j when below, R is j when not
                         pt = (r_better != below) ? pj : po;
                         // a level only wins with a cost <= err_0 (level 0 pays no penalty): if the right side is better by
                         // less than 2^-45 err_0, fl64(errL + pen) could round onto fl64(errR + pen) and the left point win
-                        const uint32_t hg = (uint32_t)__double2hiint(__dsub_rn(errL, errR)) + (45u << 20);
+                        const uint32_t hg = (uint32_t)__double2hiint(fabs(diff)) + (45u << 20);     // errL - errR = |diff| when R is better
                         slow[k] = slow[k] || (r_better && hg <= hi_d0[k] + (1u << 20));
                     }
                     g[k] = 2 * j + (below ? 1u : 0u);
@@ -758,6 +899,19 @@ int launch_notebook(const float *means, const float *stds, int64_t n, const doub
         static const int dbg = [] { const char *e = getenv("VBQ_FAST_DEBUG"); return e ? atoi(e) : 0; }();
         bool fast_ok = !plain;                      // the tie certificate wants betas in a sane range
         for (int i = 0; i < Lc; ++i) fast_ok = fast_ok && (bc.beta[i] >= 1e-12 && bc.beta[i] <= 1e18);
+        static const bool no_pruned = [] { const char *e = getenv("VBQ_NO_PRUNED"); return e && e[0] == '1'; }();
+        if (!plain && !no_pruned && Lc <= 2) {         // one or two betas per call (the notebook's own pattern): pruned descent
+            int64_t gp = gx;
+            const int64_t capp = (int64_t)num_cus() * 6 * 2;
+            if (gp > capp) gp = capp;
+            const dim3 grid((unsigned)gp), block(256);
+            if (Lc == 1 && ov) hipLaunchKernelGGL((k_quant_notebook_pruned<N, 1, true>), grid, block, 0, st, means, stds, (long)n, codebook, bc, oi, ov, vec_ok);
+            else if (Lc == 1) hipLaunchKernelGGL((k_quant_notebook_pruned<N, 1, false>), grid, block, 0, st, means, stds, (long)n, codebook, bc, oi, ov, vec_ok);
+            else if (ov) hipLaunchKernelGGL((k_quant_notebook_pruned<N, 2, true>), grid, block, 0, st, means, stds, (long)n, codebook, bc, oi, ov, vec_ok);
+            else hipLaunchKernelGGL((k_quant_notebook_pruned<N, 2, false>), grid, block, 0, st, means, stds, (long)n, codebook, bc, oi, ov, vec_ok);
+            VBQ_CHECK_LAUNCH("quant_notebook_pruned");
+            continue;
+        }
         if (fast_ok && N == 10 && Lc >= 6) {           // below that the thresholds cost more than the solves they replace
             const int rc = launch_notebook_hull10(means, stds, n, codebook, bc.beta, Lc, oi, ov, vec_ok, dbg, st);
             if (rc != 1) { if (rc != VBQ_OK) return rc; continue; }
