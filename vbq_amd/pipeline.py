@@ -324,6 +324,10 @@ class EntropyModelBuild:
             if not bool(torch.all(sums == self.global_rows)):
                 raise VBQError(f"bit-length histogram rows hold {int(sums.min())}..{int(sums.max())} samples, not global_rows = "
                                f"{self.global_rows}: the tabulated code lengths of this build are invalid")
+            sums = self.counts.sum(dim=-1, dtype=torch.int64)
+            if not bool(torch.all(sums == self.global_rows)):
+                raise VBQError(f"rank histogram rows hold {int(sums.min())}..{int(sums.max())} samples, not global_rows = "
+                               f"{self.global_rows}: the tabulated models of this build are invalid")
         for r in self.reducers:
             if r is not None:
                 r.check()
