@@ -297,6 +297,8 @@ def run_workload(name, args, torch, dist, dev, rank, world, steps, warmup, detai
         for _ in range(n):
             step()
         build.wait()
+        if world > 1:
+            build.finish_models()          # the last step's model table (sharded builds look it up one step late)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -392,7 +394,7 @@ def run_workload(name, args, torch, dist, dev, rank, world, steps, warmup, detai
                                f"{'layout change + ' if C > 1 else ''}pass 1 (solve, raw lengths, bit-length histogram) + length table + "
                                f"pass 2 (solve, corrected lengths, rank indices + rank histogram"
                                f"{', K2 overlapped in ' + str(len(build.chunks)) + ' row chunks' if len(build.chunks) > 1 else ''}) + models"
-                               f"{' + RCCL all-reduce of both histograms' if world > 1 else ''}; one code book for all ranks "
+                               f"{' + RCCL all-reduce of both histograms (the model table of a step is looked up while the next step runs)' if world > 1 else ''}; one code book for all ranks "
                                f"(second moments all-reduced)" + ("; rows of one tensor split over the ranks" if strong else ""),
                    "elements_per_gpu": E, "lambdas": L, "parallelism": f"element-sharded x{world}",
                    "launch": launch,

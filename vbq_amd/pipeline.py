@@ -177,6 +177,7 @@ class EntropyModelBuild:
         self._events = [torch.cuda.Event() for _ in self.chunks] if self.side is not None else []
         self.reducers = [None, None]
         self.works = [None, None]
+        self._models_pending = [False, False]      # sharded builds: buffers whose model table is still to be looked up
         self.timers = None             # bench.py: callable(name, phase) recording an event on the current stream
         self.collectives = True        # bench.py switches them off to measure what they cost
         if self.world > 1 and counts_dtype == torch.int32:
@@ -275,21 +276,28 @@ class EntropyModelBuild:
                 self.works[s].wait()
                 self.works[s] = None
 
+    def _models_from(self, slot):
+        """counts of buffer `slot` (global once its all-reduce is waited for) -> self.models."""
+        self.wait(slot)
+        counts = self._counts2[slot]
+        if self.lut2 is None:                              # not tabulated: NumPy on the counts, stream-ordered
+            self._model_stages[slot].enqueue()
+        else:
+            ops._lib.check(ops._lib.lib().vbq_code_lengths_from_counts(
+                ops._ptr(counts), int(counts.dtype == torch.int32), counts.numel(), ops._ptr(self.lut2),
+                self.lut2.numel(), 0, None, ops._ptr(self.models), ops._stream(counts)), "vbq_code_lengths_from_counts")
+        self._models_pending[slot] = False
+
     def finish_models(self):
-        """quantizer.py:141-146 -> f32 [L, C, T] on the device (table form), or None when the caller must take the
-        counts to the host (entropy.neg_log2_freq)."""
+        """quantizer.py:141-146 -> f32 [L, C, T] on the device (table form) for the MOST RECENT pass 2, or None when the caller
+        must take the counts to the host (entropy.neg_log2_freq)."""
         self.wait(self._slot)
         if self.models is None:
             return None
         if getattr(self, "_models_current", False):       # K2 wrote them in its flush
             return self.models
-        if self.lut2 is None:                              # not tabulated: NumPy on the counts, stream-ordered
-            self._model_stages[self._slot].enqueue()
-            self._models_current = True
-            return self.models
-        ops._lib.check(ops._lib.lib().vbq_code_lengths_from_counts(
-            ops._ptr(self.counts), int(self.counts.dtype == torch.int32), self.counts.numel(), ops._ptr(self.lut2),
-            self.lut2.numel(), 0, None, ops._ptr(self.models), ops._stream(self.counts)), "vbq_code_lengths_from_counts")
+        self._models_from(self._slot)
+        self._models_current = True
         return self.models
 
     @property
@@ -337,6 +345,16 @@ class EntropyModelBuild:
         self.pass1(mu_cb, sg_cb, level_len)
         ll, _ = self.lengths()
         self.pass2(mu_cb, sg_cb, ll)
-        if models and self.world == 1:
-            self.finish_models()
+        if models and self.models is not None:
+            if self.world == 1:
+                self.finish_models()
+            else:
+                # Sharded: this step's rank histogram is being all-reduced asynchronously; the model table of the PREVIOUS
+                # step's histogram (the other buffer: its all-reduce ran under this step's kernels) is looked up now, so
+                # every step carries one model lookup as on one GPU, one step late.  finish_models() after the last step
+                # flushes the pipeline.
+                prev = self._slot ^ 1
+                if self._models_pending[prev]:
+                    self._models_from(prev)
+                self._models_pending[self._slot] = True
         return self
