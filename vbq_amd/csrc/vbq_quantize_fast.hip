@@ -499,9 +499,6 @@ constexpr int kHullThreads = VBQ_HULL_THREADS;
 #endif
 constexpr int kHullKeys = 2048;         // 16 octaves of 128 buckets
 constexpr int kFixQueue = 192;          // K1t: deferred fix-ups per workgroup (about ten are expected per 2 300 elements)
-#ifndef VBQ_ABL
-#define VBQ_ABL 0                       // timing ablations of K1t (tools/build_variants.py); wrong results when != 0
-#endif
 struct HullSweep {
     float lam[32];          // the sweep rounded to f32, ascending
     unsigned char perm[32]; // position of lam[l] in the caller's order
@@ -522,11 +519,6 @@ __device__ __forceinline__ void hull_du_nearest(const char *tbb, float z, float 
     for (int n = 0; n <= N; ++n) {
         const int off4 = 4 * ((1 << n) - 1);
         const int top4 = off4;
-#if VBQ_ABL == 7 || VBQ_ABL == 8
-        // timing experiment (wrong results): slots that do not depend on the previous level's read -- what a bucket table
-        // on z in front of the descent could buy at most
-        g = ((__float_as_uint(z) >> (20 - n)) & ((1u << n) - 1u)) * 4u;
-#endif
         const float pj = *reinterpret_cast<const float *>(tbb + off4 + g);
         const bool below = pj < z;
         float dmin;
@@ -718,7 +710,6 @@ k_level_counts_hull(const float *__restrict__ mu, const float *__restrict__ sg, 
     const unsigned int copy = lane & (unsigned)(KC - 1);
     const int key0 = sw.key0, nkeys = sw.nkeys;
     unsigned int my_valid = 0;
-    float sink = 0.0f;
 
     const long q0 = (long)blockIdx.x * blockDim.x + threadIdx.x, qstep = (long)gridDim.x * blockDim.x;
     int it = 0;
@@ -751,13 +742,6 @@ k_level_counts_hull(const float *__restrict__ mu, const float *__restrict__ sg, 
         float du[NE][N1];
 #pragma unroll
         for (int k = 0; k < NE; ++k) hull_du_nearest<N>(tbb, m4[k], s4[k], du[k]);
-#if VBQ_ABL == 3 || VBQ_ABL == 7
-#pragma unroll
-        for (int k = 0; k < NE; ++k)
-#pragma unroll
-            for (int n = 0; n < N1; ++n) sink += du[k][n];
-        continue;
-#endif
         uint64_t fix[NE];                                      // lanes whose element k needs the fix-up
 #pragma unroll
         for (int k = 0; k < NE; ++k) {
@@ -769,10 +753,6 @@ k_level_counts_hull(const float *__restrict__ mu, const float *__restrict__ sg, 
             fix[k] = __builtin_amdgcn_ballot_w64(!(hull_max_du<N>(du[k]) < kHullBig)) | (force_slow ? ~0ull : 0ull);
 #pragma unroll
             for (int n = 0; n < N; ++n) {
-#if VBQ_ABL == 2
-                sink += Tn[n];
-                continue;
-#endif
                 float4 nb;
                 const uint32_t a = hull_position(Tn[n], key0, nkeys, lut, rec, nb);
                 const float G = hull_band(Tn[n], n, du[k][n]);
@@ -817,7 +797,6 @@ k_level_counts_hull(const float *__restrict__ mu, const float *__restrict__ sg, 
             hull_counts_fix<N>(lanes, du, tb, z, sgm, L, key0, nkeys, perm_s, lut, rec, penl, corr, force_slow);
         }
     }
-    if (VBQ_ABL != 0 && sink == 1.2345e-30f) level_counts[0] = 1;       // keeps the ablated work alive
     atomicAdd(&n_valid, my_valid);
     __syncthreads();
     // counts[l][n] = #{a_{n-1} > l} - #{a_n > l} + corrections, with #{a_{-1} > l} = all elements and #{a_N > l} = 0
