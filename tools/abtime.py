@@ -19,10 +19,18 @@ from vbq_amd import ops
 
 
 
-def timeit(fn, reps=15):
+def timeit(fn, reps=15, ramp_s=0.15):
+    """Median / minimum of `reps` event-timed calls, after an untimed ramp: the first ~50 ms of kernels after an idle gap run
+    about 10 % below the clock the device then sustains (EXPERIMENTS.md), which is more than most A/B differences."""
+    import time
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < ramp_s:
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
     for a, b in evs:
         a.record(); fn(); b.record()
