@@ -56,8 +56,9 @@ enum {
     VBQ_LAYOUT_BC = 0,
     VBQ_LAYOUT_CB = 1,
     /* vbq_quantize_f32 only: inputs channel-last [n_rows][n_ch] as the latents arrive, outputs channel-major
-     * planes [n_lambda][n_ch][n_rows] -- the solve without the two input transposes (VBQ_MODE_F32, lambdas in
-     * the fast kernel's range; otherwise VBQ_ERR_UNSUPPORTED). */
+     * planes [n_lambda][n_ch][n_rows] -- the solve without the two input transposes (VBQ_MODE_F32; three or more
+     * lambdas must lie in the fast kernel's range [1.9e-12, 1.8e19], otherwise VBQ_ERR_UNSUPPORTED; one or two
+     * lambdas take the pruned descent, which accepts any value). */
     VBQ_LAYOUT_BC_TO_CB = 2
 };
 
@@ -102,6 +103,10 @@ int vbq_device_name(int dev, char *buf, size_t buflen);
  *   d_out_zhat      optional f32, same shape: the winning code point (Z_hat).
  *   d_out_bits      optional f32, same shape: its code length (num_bits).
  *   d_workspace     vbq_quantize_workspace_bytes() bytes of device scratch.
+ *   Which kernel serves a call is an implementation detail (same answers): one or two lambdas with indices as the only
+ *   output take a descent that stops as soon as no deeper bit level can win (literal comparisons only: any lambda, any
+ *   lengths); sweeps of 16-32 lambdas with raw lengths are solved from ten thresholds per element; everything else by
+ *   the fused per-lambda kernel.
  *   N               max_bits_per_coord; kernels are built for 4 <= N <= 12 (the reference uses 10,
  *                   post_process.py:117); N = 11, 12 for channel-major planes / one code book only
  *                   (16 channel tables no longer fit the LDS); the notebook solve and the coder stop at
