@@ -534,7 +534,10 @@ __device__ __forceinline__ void nb_thresholds(const float (&dv)[11], float (&Tn)
     }
 }
 
-template <bool WITH_VAL, int CW>      // CW: words of eight 4-bit fields per column (positions 0 .. L: 5 for L <= 32, 9 for L <= 64)
+// CW: words of eight 4-bit fields per column (positions 0 .. L: 5 for L <= 32, 9 for L <= 64).  NF > 0: the sweep has exactly NF full
+// words (L >> 3 == NF) and they are emitted as ONE straight block -- all 16 NF rank reads of a lane pair in flight together --
+// instead of NF blocks with a branch and a full LDS latency each; a last partial word takes the generic code.
+template <bool WITH_VAL, int CW, int NF>
 __global__ void __launch_bounds__(256, WITH_VAL ? 2 : (CW <= 5 ? 4 : 3))
 k_quant_notebook_hull(const float *__restrict__ means, const float *__restrict__ stds, long n,
                       const double *__restrict__ codebook, NbSweep sw, uint16_t *__restrict__ out_idx,
@@ -730,8 +733,45 @@ k_quant_notebook_hull(const float *__restrict__ means, const float *__restrict__
 #pragma unroll
             for (int k = 0; k < NE; ++k) base[k] = (k * 256 + tid) * 2;            // bits 0 .. 9; the level index goes into bits 10 .. 13
             const int nfull = L >> 3;
+            if constexpr (NF > 0 && !WITH_VAL) {
+                uint32_t opq = 0;
+                asm volatile("" : "+v"(opq));                    // the row numbers are re-read every iteration (not hoisted into 2 NF x 8 SGPRs)
+                const uint32_t *pv = reinterpret_cast<const uint32_t *>(perm_s) + opq;
+                uint32_t P[NF][NE];
 #pragma unroll
-            for (int wd = 0; wd < CW - 1; ++wd) {
+                for (int wd = 0; wd < NF; ++wd)
+#pragma unroll
+                    for (int k = 0; k < NE; ++k) {
+                        P[wd][k] = (cw[wd][k] + run[k]) * 0x11111111u;
+                        run[k] = P[wd][k] >> 28;
+                    }
+#pragma unroll
+                for (int half = 0; half < NF / 2; ++half) {
+                    uint32_t v[16], pw4[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) pw4[i] = __builtin_amdgcn_readfirstlane(pv[4 * half + i]);
+#pragma unroll
+                    for (int w2 = 0; w2 < 2; ++w2)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const int wd = 2 * half + w2;
+                            uint32_t r2[NE];
+#pragma unroll
+                            for (int k = 0; k < NE; ++k) {
+                                const uint32_t sh = j < 3 ? (P[wd][k] << (10 - 4 * j)) : (P[wd][k] >> (4 * j - 10));
+                                r2[k] = *reinterpret_cast<const unsigned short *>(rkb + ((sh & 0x3c00u) | base[k]));
+                            }
+                            v[8 * w2 + j] = r2[0] | (r2[1] << 16);
+                        }
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const uint32_t rowi = (pw4[i >> 2] >> (8 * (i & 3))) & 0xffu;
+                        __builtin_nontemporal_store(v[i], reinterpret_cast<uint32_t *>(oi + (long)rowi * n));
+                    }
+                }
+            }
+#pragma unroll
+            for (int wd = (NF > 0 && !WITH_VAL) ? NF : 0; wd < CW - 1; ++wd) {
                 if (wd > nfull) break;
                 const uint2 pw = reinterpret_cast<const uint2 *>(sw.perm)[wd];      // eight row numbers, one scalar load
                 uint32_t P[NE];
@@ -866,13 +906,17 @@ int launch_notebook_hull10(const float *means, const float *stds, int64_t n, con
     const int64_t cap = (int64_t)num_cus() * (ov ? 2 : (Lc <= 32 ? 4 : 3)) * rounds;              // persistent grid: every CU's resident workgroups, two rounds
     if (gx > cap) gx = cap;
     if (gx < 1) gx = 1;
-#define VBQ_NB_HULL(V, W)                                                                                             \
-    hipLaunchKernelGGL((k_quant_notebook_hull<V, W>), dim3((unsigned)gx), dim3(256), 0, st, means, stds, (long)n, codebook, sw, oi, \
+#define VBQ_NB_HULL(V, W, F)                                                                                          \
+    hipLaunchKernelGGL((k_quant_notebook_hull<V, W, F>), dim3((unsigned)gx), dim3(256), 0, st, means, stds, (long)n, codebook, sw, oi, \
                        ov, vec_ok, dbg)
     if (ov) {
-        if (Lc <= 32) VBQ_NB_HULL(true, 5); else VBQ_NB_HULL(true, 9);
+        if (Lc <= 32) VBQ_NB_HULL(true, 5, 0); else VBQ_NB_HULL(true, 9, 0);
+    } else if (Lc == 32) {                                   // 32 betas: four full words in one straight block
+        VBQ_NB_HULL(false, 5, 4);
+    } else if ((Lc >> 3) == 6) {                             // 48 .. 55 betas (the notebook's 50): six
+        VBQ_NB_HULL(false, 9, 6);
     } else {
-        if (Lc <= 32) VBQ_NB_HULL(false, 5); else VBQ_NB_HULL(false, 9);
+        if (Lc <= 32) VBQ_NB_HULL(false, 5, 0); else VBQ_NB_HULL(false, 9, 0);
     }
 #undef VBQ_NB_HULL
     VBQ_CHECK_LAUNCH("quant_notebook_hull");
