@@ -407,7 +407,9 @@ def test_raw_sweep_threshold_kernel(ops):
     sg[5::11] = np.float32(2.0 ** -10)
     on_thr = _threshold_lambdas(mu[-6000:], sg[-6000:], tab[0], rng, 60)
     assert len(on_thr) >= 16
-    sweeps = [LAM32, LAM32[::-1], [LAM32[i] for i in rng.permutation(32)[:17]], [2.0 ** k for k in range(-10, 9)], on_thr,
+    lam16 = [float(v) for v in 2.0 ** np.linspace(-8, 7, 16)]                 # post_process.py:115: the 16-point straight emission
+    sweeps = [LAM32, LAM32[::-1], lam16, [lam16[i] for i in rng.permutation(16)],
+              [LAM32[i] for i in rng.permutation(32)[:17]], [2.0 ** k for k in range(-10, 9)], on_thr,
               [float(v) for v in np.sort(np.exp(rng.uniform(np.log(1e-3), np.log(1e3), 32)))],
               LAM32[:15],                                            # too short        -> k_quant_fast
               LAM32[:20] + LAM32[:3],                                # repeated values  -> k_quant_fast

@@ -851,7 +851,7 @@ k_level_counts_hull(const float *__restrict__ mu, const float *__restrict__ sg, 
 #ifndef VBQ_K1E_WAVES
 #define VBQ_K1E_WAVES 4
 #endif
-// LFIX = 32: the sweep has exactly 32 points (four full words of the "levels lost" column): the emission is one straight block
+// LFIX = 32 / 16: the sweep has exactly that many points (four / two full words of the "levels lost" column): the emission is one straight block
 // -- all 64 rank reads of a lane pair in flight together -- instead of four blocks with a branch and a full LDS latency each.
 template <int N, int LFIX>
 __global__ void __launch_bounds__(256, VBQ_K1E_WAVES)
@@ -1068,20 +1068,21 @@ k_quant_hull_idx(const float *__restrict__ mu, const float *__restrict__ sg, lon
 #pragma unroll
             for (int k = 0; k < NE; ++k) lbase[k] = (k * 256 + tid) * 2;           // bits 0 .. 9; the level index goes into bits 10 .. 13
             const int nfull = L >> 3;
-            if constexpr (LFIX == 32) {
+            if constexpr (LFIX == 32 || LFIX == 16) {
+                constexpr int NFW = LFIX / 8;                              // full words
                 uint32_t opq = 0;
                 asm volatile("" : "+v"(opq));
                 const uint32_t *pv = reinterpret_cast<const uint32_t *>(perm_s) + opq;
-                uint32_t P[4][NE];
+                uint32_t P[NFW][NE];
 #pragma unroll
-                for (int wd = 0; wd < 4; ++wd)
+                for (int wd = 0; wd < NFW; ++wd)
 #pragma unroll
                     for (int k = 0; k < NE; ++k) {
                         P[wd][k] = (cw[wd][k] + run[k]) * 0x11111111u;
                         run[k] = P[wd][k] >> 28;
                     }
 #pragma unroll
-                for (int half = 0; half < 2; ++half) {
+                for (int half = 0; half < NFW / 2; ++half) {
                     uint32_t v[16];
                     uint32_t pw[4];
 #pragma unroll
@@ -1529,6 +1530,9 @@ int launch_quant_hull_idx10(const float *mu, const float *sg, int64_t n_per_ch, 
     for (int i = 0; i < kMaxLambdaChunk; ++i) l32.lam[i] = i < L ? (float)lam[i] : 0.0f;
     if (L == 32)
         hipLaunchKernelGGL((k_quant_hull_idx<10, 32>), dim3((unsigned)gx, (unsigned)n_ch), dim3(256), 0, st, mu, sg, (long)n_per_ch,
+                           (long)ch_stride, (int)n_ch, table, l32, sw, vec_ok, out_idx, (long)E, dbg);
+    else if (L == 16)                                        // the sweep of post_process.py:115
+        hipLaunchKernelGGL((k_quant_hull_idx<10, 16>), dim3((unsigned)gx, (unsigned)n_ch), dim3(256), 0, st, mu, sg, (long)n_per_ch,
                            (long)ch_stride, (int)n_ch, table, l32, sw, vec_ok, out_idx, (long)E, dbg);
     else
         hipLaunchKernelGGL((k_quant_hull_idx<10, 0>), dim3((unsigned)gx, (unsigned)n_ch), dim3(256), 0, st, mu, sg, (long)n_per_ch,
