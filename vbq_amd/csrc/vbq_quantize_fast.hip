@@ -263,7 +263,10 @@ k_quant_fast(const float *__restrict__ mu, const float *__restrict__ sg, long n_
         for (int k = 0; k < NE; ++k) { m4[k] = mn[k]; s4[k] = sn[k]; }
         // The next group's loads go out BEFORE this group's stores: loads and stores share one in-order counter on gfx9
         // (vmcnt), so a load issued after the last lambda's store could only be waited for together with every store.
-        if (q + qstep < nquads) load_group(q + qstep, mn, sn);
+        {   // branch-free (the last iteration re-reads its own group): phase A stays one basic block
+            const long qn = q + qstep < nquads ? q + qstep : q;
+            load_group(qn, mn, sn);
+        }
 
         // ---------------- phase A: descent, per-level best cost + packed side info ----------------
         float du[NE][N1];
