@@ -258,6 +258,35 @@ def test_quantize_facade_channel_last_takes_the_plane_kernels(monkeypatch):
         vbq_amd.quantize(mu_d, sg_d, 1.0, table=tab_d)
 
 
+def test_rd_sums_against_numpy():
+    """vbq_rd_sums_u16: distortion and rate sums per lambda (f64) == NumPy f64 on the same indices, both layouts, with and
+    without a rate table, lambda counts on both sides of the kernel's chunk of eight."""
+    from vbq_amd import ops
+    rng = np.random.default_rng(31)
+    rows, C, T = 999, 5, 2 ** (N + 1) - 1
+    mu = rng.normal(0, 1.2, (rows, C)).astype(np.float32)
+    sg = np.exp(rng.normal(-2, 0.7, (rows, C))).astype(np.float32)
+    srt = np.sort(rng.normal(0, 1.5, (C, T)).astype(np.float32), axis=1)
+    ch = np.arange(C)[None, :]
+    for L in (1, 8, 11, 32):
+        idx = rng.integers(0, T, (L, rows, C)).astype(np.uint16)
+        rate = np.abs(rng.normal(6, 3, (L, C, T))).astype(np.float32)
+        z = np.stack([srt[ch, idx[l].astype(np.int64)] for l in range(L)]).astype(np.float64)
+        want_d = ((z - mu.astype(np.float64)) ** 2 / (2.0 * sg.astype(np.float64) ** 2)).reshape(L, -1).sum(1)
+        want_r = np.stack([rate[l][ch, idx[l].astype(np.int64)].astype(np.float64).sum() for l in range(L)])
+        got = ops.rd_sums(torch.from_numpy(mu).cuda(), torch.from_numpy(sg).cuda(), torch.from_numpy(idx).cuda(),
+                          torch.from_numpy(srt).cuda(), C, N=N, layout="bc", rate=torch.from_numpy(rate).cuda()).cpu().numpy()
+        assert np.allclose(got[:, 0], want_d, rtol=1e-12) and np.allclose(got[:, 1], want_r, rtol=1e-12)
+        got = ops.rd_sums(torch.from_numpy(np.ascontiguousarray(mu.T)).cuda(), torch.from_numpy(np.ascontiguousarray(sg.T)).cuda(),
+                          torch.from_numpy(np.ascontiguousarray(idx.transpose(0, 2, 1))).cuda(), torch.from_numpy(srt).cuda(), C, N=N,
+                          layout="cb", rate=torch.from_numpy(rate[0]).cuda()).cpu().numpy()
+        want_r0 = np.stack([rate[0][ch, idx[l].astype(np.int64)].astype(np.float64).sum() for l in range(L)])
+        assert np.allclose(got[:, 0], want_d, rtol=1e-12) and np.allclose(got[:, 1], want_r0, rtol=1e-12)
+        got = ops.rd_sums(torch.from_numpy(mu).cuda(), torch.from_numpy(sg).cuda(), torch.from_numpy(idx).cuda(),
+                          torch.from_numpy(srt).cuda(), C, N=N, layout="bc").cpu().numpy()
+        assert np.allclose(got[:, 0], want_d, rtol=1e-12) and np.all(got[:, 1] == 0)
+
+
 def test_transpose_planes_u16_and_f32():
     from vbq_amd import ops
     rng = np.random.default_rng(2)

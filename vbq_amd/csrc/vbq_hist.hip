@@ -345,34 +345,48 @@ k_gather(const uint16_t *__restrict__ idx, long n_rows, int C, int layout, long 
 // ---------------------------------------------------------------------------- rate-distortion sums
 // out[l] = { sum_e ((z - mu)^2 / (2 sigma^2)),  sum_e rate[l][c(e)][idx] }  with z = sorted table[c(e)][idx], everything
 // accumulated in f64: the two terms of the Lagrangian the solve minimises, as a report (never used by a kernel).
+constexpr int kRdChunk = 8;            // lambdas per workgroup: (mu, sigma) are read once per chunk, not once per lambda
 __global__ void __launch_bounds__(256)
 k_rd_sums(const float *__restrict__ mu, const float *__restrict__ sg, const uint16_t *__restrict__ idx, long n_rows, int C,
           int layout, long E, int T, const float *__restrict__ tab_sorted, const float *__restrict__ rate, int rate_per_lambda,
-          double *__restrict__ out) {
-    const int l = blockIdx.y;
-    const uint16_t *src = idx + (long)l * E;
-    const float *rl = rate ? rate + (rate_per_lambda ? (long)l * C * T : 0) : nullptr;
-    double sd = 0.0, sr = 0.0;
+          int L, double *__restrict__ out) {
+    const int l0 = blockIdx.y * kRdChunk;
+    double sd[kRdChunk], sr[kRdChunk];
+#pragma unroll
+    for (int j = 0; j < kRdChunk; ++j) sd[j] = sr[j] = 0.0;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (long)gridDim.x * blockDim.x) {
         const int c = (C == 1) ? 0 : (layout == VBQ_LAYOUT_BC ? (int)(e % C) : (int)(e / n_rows));
-        const int q = min((int)src[e], T - 1);
-        const double d = (double)tab_sorted[(long)c * T + q] - (double)mu[e];
-        const double s = (double)sg[e];
-        sd += d * d / (2.0 * s * s);
-        if (rl) sr += (double)rl[(long)c * T + q];
-    }
+        const double m = (double)mu[e], s = (double)sg[e];
+        const double w = 1.0 / (2.0 * s * s);
+        const float *ts = tab_sorted + (long)c * T;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        sd += __shfl_down(sd, o);
-        sr += __shfl_down(sr, o);
+        for (int j = 0; j < kRdChunk; ++j) {
+            const int l = l0 + j;
+            if (l < L) {
+                const int q = min((int)idx[(long)l * E + e], T - 1);
+                const double d = (double)ts[q] - m;
+                sd[j] += d * d * w;
+                if (rate) sr[j] += (double)rate[(rate_per_lambda ? (long)l * C * T : 0) + (long)c * T + q];
+            }
+        }
     }
-    __shared__ double part[2][4];
-    const int w = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) { part[0][w] = sd; part[1][w] = sr; }
+    __shared__ double part[2][kRdChunk][4];
+    const int w4 = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < kRdChunk; ++j) {
+        double a = sd[j], b = sr[j];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            a += __shfl_down(a, o);
+            b += __shfl_down(b, o);
+        }
+        if ((threadIdx.x & 63) == 0) { part[0][j][w4] = a; part[1][j][w4] = b; }
+    }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        atomicAdd(&out[2 * l], part[0][0] + part[0][1] + part[0][2] + part[0][3]);
-        atomicAdd(&out[2 * l + 1], part[1][0] + part[1][1] + part[1][2] + part[1][3]);
+    if (threadIdx.x < kRdChunk && l0 + (int)threadIdx.x < L) {
+        const int j = threadIdx.x;
+        atomicAdd(&out[2 * (l0 + j)], part[0][j][0] + part[0][j][1] + part[0][j][2] + part[0][j][3]);
+        atomicAdd(&out[2 * (l0 + j) + 1], part[1][j][0] + part[1][j][1] + part[1][j][2] + part[1][j][3]);
     }
 }
 
@@ -1032,12 +1046,13 @@ extern "C" int vbq_rd_sums_u16(const float *d_mu, const float *d_sigma, const ui
     if (n_rows == 0) return VBQ_OK;
     VBQ_REQUIRE(d_mu && d_sigma && d_idx && d_tab_sorted && d_out, VBQ_ERR_INVALID_ARGUMENT, "vbq_rd_sums_u16: null pointer argument");
     const int64_t E = n_rows * (int64_t)n_ch;
+    const int chunks = (n_lambda + kRdChunk - 1) / kRdChunk;
     int64_t gx = (E + 255) / 256;
-    const int64_t cap = 8192 / n_lambda + 1;
+    const int64_t cap = (int64_t)num_cus() * 8 / chunks + 1;
     if (gx > cap) gx = cap;
-    hipLaunchKernelGGL(k_rd_sums, dim3((unsigned)gx, (unsigned)n_lambda), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), d_mu,
+    hipLaunchKernelGGL(k_rd_sums, dim3((unsigned)gx, (unsigned)chunks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), d_mu,
                        d_sigma, d_idx, (long)n_rows, (int)n_ch, (int)layout, (long)E, table_size(N), d_tab_sorted, d_rate,
-                       (int)rate_per_lambda, d_out);
+                       (int)rate_per_lambda, (int)n_lambda, d_out);
     VBQ_CHECK_LAUNCH("rd_sums");
     return VBQ_OK;
 }
