@@ -1,6 +1,6 @@
 """Parity stress of the notebook kernels (K1nt thresholds for sweeps of >= 6 betas, K1n per beta otherwise) vs the literal
 2047-point brute force (C oracle of compress_coordinates, ipynb:429-443).
-    python tools/stress_notebook.py [n] [rounds]
+    python tools/stress_notebook.py [n] [rounds] [seed offset]
 Rounds cycle through: a short sweep, the notebook's 50 betas, an unsorted sweep with repeats across a launch-chunk boundary
 (dense kernel), a randomly spaced unsorted sweep of 6 to 64 betas, and an ADVERSARIAL sweep whose betas put the penalty weight of chosen elements exactly on their own
 level-change thresholds (T_n = max_j min_i (err_i - err_j) / (j - i), computed here in float64) -- the case K1nt's guard bands
@@ -43,7 +43,7 @@ def threshold_betas(means, stds, pts, lens, rng, count):
 
 
 def main():
-    rng = np.random.default_rng(11)
+    rng = np.random.default_rng(11 + (int(sys.argv[3]) if len(sys.argv) > 3 else 0))
     dev = torch.device("cuda")
     tot = bad = 0
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 300000

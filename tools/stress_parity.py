@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Large randomized parity stress: HIP K1 (fast plane kernel) vs the C oracle, bit for bit.
-    python tools/stress_parity.py [--n 4000000] [--rounds 6] [--levels]
+    python tools/stress_parity.py [--n 4000000] [--rounds 6] [--levels | --small] [--seed K]
 --levels: the counting kernels instead (K1t thresholds for raw lengths, K1h dense for corrected ones): bit-length
 histograms of windows of 20 000 elements against np.bincount of the oracle's levels, with varied lambda sweeps
 (geometric, random spacing, unsorted, short) -- one wrong element shows up as two wrong counts.
@@ -67,7 +67,7 @@ def sweep(rng, r):
 def levels_main(args):
     from oracle import vbq_oracle as O
     dev = torch.device("cuda")
-    rng = np.random.default_rng(777)
+    rng = np.random.default_rng(777 + args.seed)
     lev = O.levels_of_sorted_ranks(N)
     W = 20_000
     total = bad = 0
@@ -100,7 +100,7 @@ def small_main(args):
     raw and corrected lengths (zero and huge overheads included: penalties that never prune / prune at once), all table
     kinds.  The oracle solves the whole 32-point sweep once per round; the GPU is called per lambda / pair."""
     dev = torch.device("cuda")
-    rng = np.random.default_rng(4242)
+    rng = np.random.default_rng(4242 + args.seed)
     total = bad = 0
     kinds = ["raw", "corr", "dup", "t", "corr", "raw"]
     for r in range(args.rounds):
@@ -136,13 +136,14 @@ def main():
     ap.add_argument("--rounds", type=int, default=6)
     ap.add_argument("--levels", action="store_true")
     ap.add_argument("--small", action="store_true")
+    ap.add_argument("--seed", type=int, default=0, help="added to every generator's seed: a repeated soak sees new data")
     args = ap.parse_args()
     if args.levels:
         return levels_main(args)
     if args.small:
         return small_main(args)
     dev = torch.device("cuda")
-    rng = np.random.default_rng(2024)
+    rng = np.random.default_rng(2024 + args.seed)
     total = bad = 0
     kinds = ["raw", "corr", "dup", "t", "raw", "corr"]
     for r in range(args.rounds):
