@@ -257,6 +257,18 @@ def event_ms(torch, fn, steps, warmup):
     return float(np.mean([a.elapsed_time(b) for a, b in ev]))
 
 
+
+def compact(o, keep=("value", "ms_per_step")):
+    """The printed line: floats at 7 significant digits (the raw doubles doubled its length; `value`, `ms_per_step` and the
+    oracle comparison's max_rel_diff keep theirs)."""
+    if isinstance(o, dict):
+        return {k: (v if k in keep and isinstance(v, float) else compact(v, keep)) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [compact(v, keep) for v in o]
+    if isinstance(o, float) and o == o and abs(o) != float("inf"):
+        return float(f"{o:.7g}")
+    return o
+
 def rd_curve(ops, mu, sg, idx, tab_h, models, C, layout, lambdas, E):
     """Rate / distortion / Lagrangian per lambda of the indices `idx` on the device (vbq_rd_sums_u16, f64)."""
     import torch
@@ -625,7 +637,7 @@ def main():
 
     if args.notebook:
         out = run_notebook(args, torch, dev, cpu=not args.no_cpu_baseline)
-        print(json.dumps(out))
+        print(json.dumps(compact(out)))
         return
 
     res = run_workload(args.workload, args, torch, dist, dev, rank, world, args.steps, args.warmup,
@@ -710,7 +722,7 @@ def main():
         if rank == 0:
             out["workloads"] = others
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(compact(out)))
     if world > 1:
         dist.destroy_process_group()
     if rank == 0:
