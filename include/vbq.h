@@ -133,9 +133,10 @@ int vbq_n_bit_intervals_f32(const float *d_z_cb, int64_t n_rows, int32_t n_ch, c
 
 /* The same solve on rows [row_begin, row_end) of the full arrays (pointers, n_rows and output addressing are those
  * of the whole tensor): lets the caller cut one pass into chunks and run K2 on chunk j (another stream) while K1
- * works on chunk j + 1.  workgroups_per_cu = 0: default grid; 1..5: a persistent grid of that many workgroups per
- * CU (4 leaves the LDS and the wave slots a concurrently running K2 needs).  For planes (VBQ_LAYOUT_CB) the
- * vector path wants row_begin % 8 == 0. */
+ * works on chunk j + 1.  workgroups_per_cu = 0: default grid (the 4 workgroups per CU that fit, resident from start to
+ * end, issue priority rotating over them); 1..5: a resident grid of that many workgroups per CU (at most the 4 that
+ * fit; 3 leaves wave slots and LDS for a concurrently running K2).  For planes (VBQ_LAYOUT_CB) the vector path wants
+ * row_begin % 8 == 0. */
 int vbq_quantize_rows_f32(const float *d_mu, const float *d_sigma, int64_t n_rows, int32_t n_ch,
                           int32_t layout, const float *d_table_lm, const float *d_level_len,
                           const double *h_lambdas, int32_t n_lambda, int32_t N, int32_t mode,

@@ -31,6 +31,31 @@ int num_cus();
         }                                                                             \
     } while (0)
 
+// Issue priority in resident ("persistent") grids.  The SIMD arbitrates instruction issue between its waves by priority, then
+// by AGE: with every wave at priority 0 the oldest one runs nearly unimpeded and the youngest gets the leftover slots.  In a grid
+// whose workgroups are all resident from start to end that order never changes: the oldest wave of a SIMD finishes early, the
+// youngest is left to run alone at a fraction of the issue rate (K1 on Kodak-24: 394 us with 4 workgroups per CU x 18
+// iterations, against 358 us for a dynamic grid of 18 x 4 although that one has a half-empty last round).  Rotating the
+// priority over the resident waves -- wave slot + iteration, modulo 4 -- lets them progress at the same pace and finish
+// together: K1t 138 -> 122 us, K1 394 -> 346 us (EXPERIMENTS.md, "issue priority").  s_setprio takes an immediate.
+__device__ __forceinline__ void set_issue_priority(unsigned int p) {
+    p = __builtin_amdgcn_readfirstlane(p) & 3u;
+    if (p == 0) __builtin_amdgcn_s_setprio(0);
+    else if (p == 1) __builtin_amdgcn_s_setprio(1);
+    else if (p == 2) __builtin_amdgcn_s_setprio(2);
+    else __builtin_amdgcn_s_setprio(3);
+}
+// The wave's slot on its SIMD (HW_ID[3:0]): distinct for the waves that compete for one SIMD's issue cycles.
+__device__ __forceinline__ unsigned int wave_slot() { return __builtin_amdgcn_s_getreg((3 << 11) | 4); }
+// One step of the rotation, at the top of a kernel's element loop: `rot` starts at wave_slot() and walks 3, 2, 1, 0, 3, ...
+// (-DVBQ_NO_ISSUE_ROTATION builds the kernels without it, for A/B timing).
+__device__ __forceinline__ void rotate_issue_priority(unsigned int &rot) {
+#ifndef VBQ_NO_ISSUE_ROTATION
+    set_issue_priority(rot);
+    rot += 3u;
+#endif
+}
+
 constexpr int kWave = 64;
 constexpr int kTileChannels = 16;   // channel tables resident in LDS per workgroup (tiled kernel)
 constexpr int kMaxLambdaChunk = 32; // lambdas handled per launch (penalty table staged in LDS)

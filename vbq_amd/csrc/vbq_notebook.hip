@@ -349,7 +349,9 @@ k_quant_notebook_pruned(const float *__restrict__ means, const float *__restrict
     for (int l = 0; l < LL; ++l) tb2[l] = (float)(2.0 * bc.beta[l]);
     const char *tbb = reinterpret_cast<const char *>(tb);
     const long npairs = (n + 1) >> 1;
+    unsigned int rot = wave_slot();
     for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < npairs; q += (long)gridDim.x * blockDim.x) {
+        rotate_issue_priority(rot);                            // resident grid: see vbq_common.h
         const long i0 = q * 2;
         const bool full = vec_ok && (i0 + 2 <= n);
         float m2[NE], s2[NE];
@@ -582,7 +584,9 @@ k_quant_notebook_hull(const float *__restrict__ means, const float *__restrict__
     const unsigned int lane = tid & 63u;
     const long npairs = (n + 1) >> 1;
     const int key0 = sw.key0, nkeys = sw.nkeys;
+    unsigned int rot = wave_slot();
     for (long q = (long)blockIdx.x * blockDim.x + tid; q < npairs; q += (long)gridDim.x * blockDim.x) {
+        rotate_issue_priority(rot);                            // resident grid: see vbq_common.h
         const long i0 = q * 2;
         const bool full = vec_ok && (i0 + 2 <= n);
         float m2[NE], s2[NE];

@@ -255,7 +255,10 @@ k_quant_fast(const float *__restrict__ mu, const float *__restrict__ sg, long n_
 #pragma unroll
     for (int k = 0; k < NE; ++k) { mn[k] = 0.0f; sn[k] = 1.0f; }
     if (q0 < nquads) load_group(q0, mn, sn);
+    const bool resident = (vec_ok & 4) != 0;                // the launcher sized the grid to the resident workgroups
+    unsigned int rot = wave_slot();
     for (long q = q0; q < nquads; q += qstep) {
+        if (resident) __builtin_amdgcn_s_setprio(3);          // phase A (a chain of LDS round trips) goes first
         const long i0 = q * NE;
         const bool full = (vec_ok & 1) && (i0 + NE <= n_per_ch);
         float m4[NE], s4[NE];
@@ -321,6 +324,10 @@ k_quant_fast(const float *__restrict__ mu, const float *__restrict__ sg, long n_
         }
 
         // ---------------- phase B: one solve per lambda ----------------
+        if (resident) {                                       // the VALU-dense part: priorities 0..2 in rotation (vbq_common.h)
+            set_issue_priority(rot % 3u);
+            ++rot;
+        }
         for (int l = 0; l < L; ++l) {
             const float *pp = penl + l * PS;
             float p[N1];
@@ -716,7 +723,9 @@ k_level_counts_hull(const float *__restrict__ mu, const float *__restrict__ sg, 
 
     const long q0 = (long)blockIdx.x * blockDim.x + threadIdx.x, qstep = (long)gridDim.x * blockDim.x;
     int it = 0;
+    unsigned int rot = wave_slot();
     for (long q = q0; q < nquads; q += qstep, ++it) {
+        rotate_issue_priority(rot);                            // resident grid: see vbq_common.h
         const long i0 = q * NE;
         const bool full = (vec_ok & 1) && (i0 + NE <= n_per_ch);
         float m4[NE], s4[NE];
@@ -907,7 +916,9 @@ k_quant_hull_idx(const float *__restrict__ mu, const float *__restrict__ sg, lon
     const char *tbb = reinterpret_cast<const char *>(tb);
     const unsigned int lane = tid & 63u;
 
+    unsigned int rot = wave_slot();
     for (long q = (long)blockIdx.x * blockDim.x + tid; q < npairs; q += (long)gridDim.x * blockDim.x) {
+        rotate_issue_priority(rot);                            // resident grid: see vbq_common.h
         const long i0 = q * NE;
         const bool full = (vec_ok & 1) && (i0 + NE <= n_per_ch);
         float m4[NE], s4[NE];
@@ -1235,7 +1246,9 @@ k_quant_pruned(const float *__restrict__ mu, const float *__restrict__ sg, long 
     const char *tbb = reinterpret_cast<const char *>(tb);
     const unsigned int lane = threadIdx.x & 63u;
 
+    unsigned int rot = wave_slot();
     for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < npairs; q += (long)gridDim.x * blockDim.x) {
+        rotate_issue_priority(rot);                            // resident grid: see vbq_common.h
         const long i0 = q * NE;
         const bool full = (vec_ok & 1) && (i0 + NE <= n_per_ch);
         float m4[NE], s4[NE];
@@ -1374,21 +1387,36 @@ int launch_quant_fast(const float *mu, const float *sg, int64_t n_per_ch, int64_
                       unsigned long long *level_counts, int wg_per_cu, hipStream_t st) {
     const int64_t nquads = (n_per_ch + kFastNE - 1) / kFastNE;
     int64_t gx = (nquads + kFastThreads - 1) / kFastThreads;
-    // 3 (NE=4: 53 KB LDS each) / 5 (NE=2) workgroups per CU fit; keep every channel's share balanced.
-    // wg_per_cu < 5 leaves LDS and wave slots for a kernel of another stream (K2 overlapping this launch).
-    const int per_cu = kFastNE == 4 ? 3 : (wg_per_cu >= 1 && wg_per_cu <= 5 ? wg_per_cu : 5);
-    int64_t cap = (int64_t)num_cus() * per_cu * (wg_per_cu >= 1 ? 1 : 4) / n_ch;
+    // A RESIDENT grid: 4 workgroups per CU (110 VGPRs: four waves per SIMD; 3 with NE=4) that stay from start to end, every
+    // channel's share balanced, the issue priority rotating over them (vbq_common.h) -- 346 us on Kodak-24 against 358 us
+    // for 18 short-lived workgroups per channel and 394 us for the same resident grid without the rotation.
+    // wg_per_cu < 4 leaves LDS and wave slots for a kernel of another stream (K2 overlapping this launch); 5 is taken as 4
+    // (a fifth workgroup per CU would only wait for a slot: 444 us).
+    static const bool dynamic_grid = [] { const char *e = getenv("VBQ_K1_DYNAMIC"); return e && e[0] == '1'; }();   // A/B switch
+    const bool explicit_wgs = wg_per_cu >= 1 && wg_per_cu <= 5;
+    const int fit = kFastNE == 4 ? 3 : 4;
+    const int per_cu = explicit_wgs ? (wg_per_cu < fit ? wg_per_cu : fit) : (dynamic_grid ? 5 : fit);
+    int64_t cap = (int64_t)num_cus() * per_cu * (!explicit_wgs && dynamic_grid ? 4 : 1) / n_ch;
+    const bool resident = !(dynamic_grid && !explicit_wgs) && (int64_t)n_ch <= (int64_t)num_cus() * per_cu;
+    if (resident) vec_ok |= 4;
     if (cap < 1) cap = 1;
     if (gx > cap) {
-        // every workgroup walks ceil(iters / gx) chunks: pick the gx in [cap/2, cap] that wastes the
-        // fewest chunk slots (e.g. 72 chunks per channel: 18 workgroups x 4, not 20 x 3.6)
         const int64_t iters = gx;
-        int64_t best = cap, best_pad = ((iters + cap - 1) / cap) * cap - iters;
-        for (int64_t g = cap - 1; g >= (cap + 1) / 2 && best_pad > 0; --g) {
-            const int64_t pad = ((iters + g - 1) / g) * g - iters;
-            if (pad * best < best_pad * g) { best = g; best_pad = pad; }
+        if (resident) {
+            // all workgroups are resident: what counts is the number of iterations of the busiest one, R = ceil(iters / cap);
+            // the fewest workgroups that still need only R keep the tail balanced (as K1t's launcher)
+            const int64_t rounds_needed = (iters + cap - 1) / cap;
+            gx = (iters + rounds_needed - 1) / rounds_needed;
+        } else {
+            // every workgroup walks ceil(iters / gx) chunks: pick the gx in [cap/2, cap] that wastes the
+            // fewest chunk slots (e.g. 72 chunks per channel: 18 workgroups x 4, not 20 x 3.6)
+            int64_t best = cap, best_pad = ((iters + cap - 1) / cap) * cap - iters;
+            for (int64_t g = cap - 1; g >= (cap + 1) / 2 && best_pad > 0; --g) {
+                const int64_t pad = ((iters + g - 1) / g) * g - iters;
+                if (pad * best < best_pad * g) { best = g; best_pad = pad; }
+            }
+            gx = best;
         }
-        gx = best;
         // count mode: a 16-bit partial counter (16 words x 2 halves per (lambda, level)) takes at most 64 / 32 lanes x the waves of
         // a workgroup x the elements of a lane per iteration
         constexpr int64_t max_iters = 65000 / ((64 / 32) * (kFastThreads / 64) * kFastNE);
@@ -1418,7 +1446,8 @@ int launch_quant_pruned(const float *mu, const float *sg, int64_t n_per_ch, int6
     if (off || L < 1 || L > kPrunedMaxL) return 1;
     const int64_t npairs = (n_per_ch + 1) / 2;
     int64_t gx = (npairs + 255) / 256;
-    int64_t cap = (int64_t)num_cus() * 4 * 2 / n_ch;            // 4 workgroups per CU resident, two rounds
+    int64_t cap = (int64_t)num_cus() * 4 / n_ch;               // the 4 workgroups per CU that are resident (one round: with the
+                                                                // priority rotation 71 us at lambda = 2^-8, two rounds 79, no rotation 74)
     if (cap < 1) cap = 1;
     if (gx > cap) gx = cap;
     static const int dbg = [] { const char *e = getenv("VBQ_FAST_DEBUG"); return e ? atoi(e) : 0; }();

@@ -172,7 +172,7 @@ class EntropyModelBuild:
             # chunked form stays available (n_chunks > 1) for experiments; the default is one launch each.
             n_chunks = 1
         self.chunks = chunk_bounds(self.rows, n_chunks)
-        self.k1_workgroups_per_cu = 4  # of 5 that fit: the fifth's LDS and wave slots are K2's while they overlap
+        self.k1_workgroups_per_cu = 3  # of the 4 that fit: the fourth's LDS and wave slots are K2's while they overlap (chunked form only)
         self.side = torch.cuda.Stream(device=self.dev) if len(self.chunks) > 1 else None
         self._events = [torch.cuda.Event() for _ in self.chunks] if self.side is not None else []
         self.reducers = [None, None]
