@@ -632,7 +632,9 @@ int launch_hist_assign(const uint16_t *idx, int64_t n_rows, int32_t n_ch, int32_
                        int64_t lut_n, float *models, hipStream_t st) {
     const int64_t E = n_rows * (int64_t)n_ch;
     const int vec_ok = reinterpret_cast<uintptr_t>(idx) % 2 == 0;           // every row finds its own 16-byte boundary (k_hist_flat)
-    // last channel first (measured on the Kodak-24 build: 0.7745 against 0.7793 ms per step, three runs each)
+    // last channel first (measured on the Kodak-24 build of round 2, whose K1 walked the channels in order: 0.7745 against
+    // 0.7793 ms per step, three runs each; K1's resident grid of round 3 writes all channels side by side, so what is still in
+    // the memory-side cache is the tail of EVERY row and the order no longer matters)
     if (n_ch <= 65535)
         hipLaunchKernelGGL((k_hist_flat<N, CountT>), dim3(1u, (unsigned)L, (unsigned)n_ch), dim3(kHistThreads), 0, st, idx, (long)n_rows,
                            (long)n_rows, (int)n_ch, (long)E, counts, vec_ok, 2, lut, (long)lut_n, models);
