@@ -116,6 +116,10 @@ def main():
         cnt = torch.zeros((L, C, 2047), dtype=torch.int32, device=dev)
         med, best = timeit(lambda: ops.histogram_models(idx, C, cnt, N=N_BITS))
         out("K2 histogram_models L=32", med, best, f"frac {2*L*E/med/1e6/8000:.3f}")
+        lut = torch.rand(rows + 4096, device=dev)                   # any table: the lookup's cost does not depend on its values
+        mdl = torch.empty((L, C, 2047), dtype=torch.float32, device=dev)
+        med, best = timeit(lambda: ops.histogram_models(idx, C, cnt, N=N_BITS, lut=lut, models=mdl))
+        out("K2 + model lookup in the flush", med, best, f"frac {2*L*E/med/1e6/8000:.3f}")
     if "k1nt" in what:
         from vbq_amd import embeddings as Emb
         n = 10_000_000

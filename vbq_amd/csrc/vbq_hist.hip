@@ -119,7 +119,9 @@ k_hist_flat(const uint16_t *__restrict__ idx, long n_per_ch, long ch_stride, int
         for (int u = 0; u < U; ++u) A[u] = *reinterpret_cast<const uint4 *>(src + (q + u * stride) * 8);
         q += U * stride;
     }
-    for (int i = threadIdx.x; i < 2048; i += blockDim.x) reinterpret_cast<uint4 *>(h)[i] = make_uint4(0, 0, 0, 0);   // 32 KB
+#pragma unroll
+    for (int r = 0; r < 2048 / kHistThreads; ++r)                                                  // 32 KB
+        reinterpret_cast<uint4 *>(h)[(int)threadIdx.x + r * kHistThreads] = make_uint4(0, 0, 0, 0);
     __syncthreads();
     while (haveA) {
         const bool haveB = full(q, U);
@@ -155,22 +157,46 @@ k_hist_flat(const uint16_t *__restrict__ idx, long n_per_ch, long ch_stride, int
     if (blockIdx.x == 0 && (long)threadIdx.x < head) atomicAdd(&h[kHistCopies * bin_slot<N>(src0[threadIdx.x])], 1u);
     __syncthreads();
     CountT *dst = counts + ((long)l * C + c) * T;
-    for (int i = threadIdx.x; i < T; i += blockDim.x) {
-        unsigned int v;
+    // Flush, the bins of a thread first read and summed, then written (and looked up) together: the LDS reads, the table
+    // gathers and the stores of its FI bins overlap instead of following each other through per-bin branches.
+    constexpr int FI = (T + kHistThreads - 1) / kHistThreads;
+    unsigned int v[FI];
+#pragma unroll
+    for (int r = 0; r < FI; ++r) {
+        const int i = (int)threadIdx.x + r * kHistThreads;
+        const int ii = i < T ? i : T - 1;
         if constexpr (kHistCopies == 4) {
-            const uint4 q4 = reinterpret_cast<const uint4 *>(h)[bin_slot<N>(i)];
-            v = (q4.x + q4.y) + (q4.z + q4.w);
+            const uint4 q4 = reinterpret_cast<const uint4 *>(h)[bin_slot<N>(ii)];
+            v[r] = (q4.x + q4.y) + (q4.z + q4.w);
         } else if constexpr (kHistCopies == 2) {
-            const uint2 q2 = reinterpret_cast<const uint2 *>(h)[bin_slot<N>(i)];
-            v = q2.x + q2.y;
+            const uint2 q2 = reinterpret_cast<const uint2 *>(h)[bin_slot<N>(ii)];
+            v[r] = q2.x + q2.y;
         } else {
-            v = h[bin_slot<N>(i)];
+            v[r] = h[bin_slot<N>(ii)];
         }
-        if (assign) {
-            dst[i] = (CountT)v;
-            if (models) models[((long)l * C + c) * T + i] = assign_lut[(long)v < lut_n ? (long)v : lut_n - 1];
-        } else if (v) {
-            atomicAdd(&dst[i], (CountT)v);
+    }
+    if (assign) {
+#pragma unroll
+        for (int r = 0; r < FI; ++r) {
+            const int i = (int)threadIdx.x + r * kHistThreads;
+            if (i < T) dst[i] = (CountT)v[r];
+        }
+        if (models) {
+            float m[FI];
+#pragma unroll
+            for (int r = 0; r < FI; ++r) m[r] = assign_lut[(long)v[r] < lut_n ? (long)v[r] : lut_n - 1];
+            float *mdst = models + ((long)l * C + c) * T;
+#pragma unroll
+            for (int r = 0; r < FI; ++r) {
+                const int i = (int)threadIdx.x + r * kHistThreads;
+                if (i < T) mdst[i] = m[r];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < FI; ++r) {
+            const int i = (int)threadIdx.x + r * kHistThreads;
+            if (i < T && v[r]) atomicAdd(&dst[i], (CountT)v[r]);
         }
     }
 }
