@@ -467,6 +467,33 @@ __global__ void __launch_bounds__(256)
 k_transpose_v4(const float *__restrict__ in, long rows, long cols, float *__restrict__ out) {
     __shared__ float tile[64][65];
     const long r0 = (long)blockIdx.y * 64, c0 = (long)blockIdx.x * 64;
+    if (r0 + 64 <= rows && c0 + 64 <= cols) {
+        // whole tile (workgroup-uniform): the four loads of a thread go out together, then the LDS writes -- with the bounds
+        // test around every access each load was waited for before the next one was issued
+        float4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = threadIdx.x + 256 * k, lr = i >> 4, lc = (i & 15) * 4;
+            v[k] = *reinterpret_cast<const float4 *>(in + (r0 + lr) * cols + c0 + lc);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = threadIdx.x + 256 * k, lr = i >> 4, lc = (i & 15) * 4;
+            tile[lr][lc] = v[k].x; tile[lr][lc + 1] = v[k].y; tile[lr][lc + 2] = v[k].z; tile[lr][lc + 3] = v[k].w;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = threadIdx.x + 256 * k, lc = i >> 4, lr = (i & 15) * 4;
+            v[k] = make_float4(tile[lr][lc], tile[lr + 1][lc], tile[lr + 2][lc], tile[lr + 3][lc]);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = threadIdx.x + 256 * k, lc = i >> 4, lr = (i & 15) * 4;
+            *reinterpret_cast<float4 *>(out + (c0 + lc) * rows + r0 + lr) = v[k];
+        }
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int i = threadIdx.x + 256 * k, lr = i >> 4, lc = (i & 15) * 4;
@@ -500,6 +527,33 @@ k_transpose_batched_vec(const T *__restrict__ in, long rows, long cols, T *__res
     in += (long)blockIdx.z * rows * cols;
     out += (long)blockIdx.z * rows * cols;
     const long r0 = (long)blockIdx.y * 64, c0 = (long)blockIdx.x * 64;
+    if (r0 + 64 <= rows && c0 + 64 <= cols) {                  // whole tile: loads together, then LDS (see k_transpose_v4)
+        Vec v[PER];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int i = threadIdx.x + 256 * k, lr = i / VPR, lc = (i % VPR) * V;
+            v[k] = *reinterpret_cast<const Vec *>(in + (r0 + lr) * cols + c0 + lc);
+        }
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int i = threadIdx.x + 256 * k, lr = i / VPR, lc = (i % VPR) * V;
+#pragma unroll
+            for (int e = 0; e < V; ++e) tile[lr][lc + e] = v[k].e[e];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int i = threadIdx.x + 256 * k, lc = i / VPR, lr = (i % VPR) * V;
+#pragma unroll
+            for (int e = 0; e < V; ++e) v[k].e[e] = tile[lr + e][lc];
+        }
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int i = threadIdx.x + 256 * k, lc = i / VPR, lr = (i % VPR) * V;
+            *reinterpret_cast<Vec *>(out + (c0 + lc) * rows + r0 + lr) = v[k];
+        }
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
         const int i = threadIdx.x + 256 * k, lr = i / VPR, lc = (i % VPR) * V;
