@@ -33,7 +33,7 @@ def cycles(m):
 
 def compile_asm(src, defs):
     out = tempfile.mktemp(suffix=".s")
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-DVBQ_ONLY_N10",
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "-DVBQ_ONLY_N10",
            "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "vbq_amd", "csrc"), "--cuda-device-only", "-S", src, "-o", out] + defs
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode:

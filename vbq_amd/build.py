@@ -24,7 +24,10 @@ HIP_SOURCES = ["vbq_api.hip", "vbq_quantize.hip", "vbq_quantize_fast.hip", "vbq_
 LINK_LIBS = ["-ldl"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
                # every f32/f64 op of the reference is a separately rounded op: never contract a*b+c
-               "-ffp-contract=off", "-fno-fast-math"]
+               "-ffp-contract=off", "-fno-fast-math",
+               # no SLP vectorisation: the v_pk_add/mul_f32 pairs it forms issue at the rate of two scalar ops but need
+               # their operands in aligned register pairs -- the moves cost K1t 3 %, K1e 5 %, the one-lambda kernel 7 %
+               "-fno-slp-vectorize"]
 
 
 def _newer(target, deps):
