@@ -183,9 +183,6 @@ __device__ VBQ_SLOW_INLINE uint32_t exact_rank_scan(const float *tb, float z, fl
 // first entropy-model pass needs: no 2 B per solve written, no K2 pass reading them back.  The LDS column that
 // parks the packed rank / gap words in modes 0 / 1 holds the counters instead: [L][N+1] x 32 sixteen-bit copies
 // (16 words x 2 halves per (lambda, level); lane & 15 picks the word, lane & 16 the half).
-#ifdef VBQ_K1_STAMP
-__device__ unsigned long long g_k1_stamp[2 * 8192];
-#endif
 template <int N, int MODE>
 __global__ void __launch_bounds__(kFastThreads, VBQ_FAST_WAVES)
 k_quant_fast(const float *__restrict__ mu, const float *__restrict__ sg, long n_per_ch, long ch_stride, int C,
@@ -258,10 +255,6 @@ k_quant_fast(const float *__restrict__ mu, const float *__restrict__ sg, long n_
 #pragma unroll
     for (int k = 0; k < NE; ++k) { mn[k] = 0.0f; sn[k] = 1.0f; }
     if (q0 < nquads) load_group(q0, mn, sn);
-#ifdef VBQ_K1_STAMP
-    const unsigned int lin_dbg = blockIdx.x + gridDim.x * blockIdx.y;
-    if (threadIdx.x == 0 && lin_dbg < 8192) g_k1_stamp[2 * lin_dbg] = __builtin_amdgcn_s_memrealtime();
-#endif
     const bool resident = (vec_ok & 4) != 0;                // the launcher sized the grid to the resident workgroups
     unsigned int rot = wave_slot();
     for (long q = q0; q < nquads; q += qstep) {
@@ -463,10 +456,6 @@ k_quant_fast(const float *__restrict__ mu, const float *__restrict__ sg, long n_
             }
         }
     }
-#ifdef VBQ_K1_STAMP
-    __syncthreads();
-    if (threadIdx.x == 0 && lin_dbg < 8192) g_k1_stamp[2 * lin_dbg + 1] = __builtin_amdgcn_s_memrealtime();
-#endif
     if constexpr (COUNT) {
         __syncthreads();
         for (int i = threadIdx.x; i < L * N1; i += blockDim.x) {
@@ -1598,8 +1587,3 @@ VBQ_FOR_EACH_N(VBQ_INST_PRUNED)
 
 }  // namespace vbq
 
-#ifdef VBQ_K1_STAMP
-extern "C" int vbq_debug_k1_stamps(unsigned long long *host, int n) {
-    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(vbq::g_k1_stamp), sizeof(unsigned long long) * n);
-}
-#endif
