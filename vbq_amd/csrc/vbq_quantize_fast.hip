@@ -324,9 +324,9 @@ k_quant_fast(const float *__restrict__ mu, const float *__restrict__ sg, long n_
         }
 
         // ---------------- phase B: one solve per lambda ----------------
-        if (resident) {                                       // the VALU-dense part: priorities 0..2 in rotation (vbq_common.h)
-            set_issue_priority(rot % 3u);
-            ++rot;
+        if (resident) {                                       // the VALU-dense part: the four levels in rotation (vbq_common.h);
+            set_issue_priority(rot);                            // with three (0..2 under phase A's) two of the four waves always
+            rot += 3u;                                          // shared a level and age decided between them: 350 -> 335 us
         }
         for (int l = 0; l < L; ++l) {
             const float *pp = penl + l * PS;
@@ -1388,7 +1388,7 @@ int launch_quant_fast(const float *mu, const float *sg, int64_t n_per_ch, int64_
     const int64_t nquads = (n_per_ch + kFastNE - 1) / kFastNE;
     int64_t gx = (nquads + kFastThreads - 1) / kFastThreads;
     // A RESIDENT grid: 4 workgroups per CU (110 VGPRs: four waves per SIMD; 3 with NE=4) that stay from start to end, every
-    // channel's share balanced, the issue priority rotating over them (vbq_common.h) -- 346 us on Kodak-24 against 358 us
+    // channel's share balanced, the issue priority rotating over them (vbq_common.h) -- 335 us on Kodak-24 against 358 us
     // for 18 short-lived workgroups per channel and 394 us for the same resident grid without the rotation.
     // wg_per_cu < 4 leaves LDS and wave slots for a kernel of another stream (K2 overlapping this launch); 5 is taken as 4
     // (a fifth workgroup per CU would only wait for a slot: 444 us).
