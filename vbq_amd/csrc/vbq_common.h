@@ -37,7 +37,8 @@ int num_cus();
 // youngest is left to run alone at a fraction of the issue rate (K1 on Kodak-24: 394 us with 4 workgroups per CU x 18
 // iterations, against 358 us for a dynamic grid of 18 x 4 although that one has a half-empty last round).  Rotating the
 // priority over the resident waves -- wave slot + iteration, modulo 4 -- lets them progress at the same pace and finish
-// together: K1t 138 -> 122 us, K1 394 -> 346 us (EXPERIMENTS.md, "issue priority").  s_setprio takes an immediate.
+// together: K1t 138 -> 122 us, K1 394 -> 335 us (EXPERIMENTS.md, "issue priority").  All four levels are used: two waves on one
+// level are ordered by age again.  s_setprio takes an immediate.
 __device__ __forceinline__ void set_issue_priority(unsigned int p) {
     p = __builtin_amdgcn_readfirstlane(p) & 3u;
     if (p == 0) __builtin_amdgcn_s_setprio(0);
