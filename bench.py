@@ -23,10 +23,12 @@ Every timed region is exactly K steps between synchronisations; in front of it, 
 repeated UNTIMED for 0.3 s (`clock_ramp`, VBQ_BENCH_RAMP_S) so that the timed steps run at the clock the device sustains under
 this load -- after an idle gap the first ~50 ms of kernels run about 10 % slower, and W steps of 0.75 ms are over before that.
 
-Prints ONE JSON line (rank 0).
+Prints ONE compact JSON line (rank 0, the LAST line of stdout, below 4 KB: `headline`) and writes the full record --
+everything listed below in full -- to --full-record (default bench_full.json next to this file).  `python bench.py --gpus N`
+started by hand starts its own N ranks (`launch_ranks`); under torch.distributed.run it is one of them.
   roofline       the dominant kernel (pass 2's K1, k_quant_fast): ALGORITHMIC bytes -- 8 B read per element + 2 B written
-                 per (element, lambda) -- over its event-timed launches against 8 TB/s.  The committed counters say what
-                 bounds it: VALU issue (bound = "valu"); the HBM fraction is what that issue rate moves.
+                 per (element, lambda) -- over its event-timed launches against 8 TB/s (bound = "hbm").  The committed
+                 counters say what keeps it below that: VALU issue (`limited_by`, `valu_issue_frac`).
   rd_curve       rate (bits per latent from the entropy models, quantizer.py:226-228), distortion
                  sum((z - mu)^2 / (2 sigma^2)) / E and Lagrangian for every lambda of the sweep, on the whole tensor (f64
                  device reduction) and, on the parity sample, next to the oracle's (max_rel_diff <= 1e-5 asserted).
@@ -269,6 +271,110 @@ def compact(o, keep=("value", "ms_per_step")):
         return float(f"{o:.7g}")
     return o
 
+LINE_LIMIT = 4096          # the driver keeps the tail of stdout: the LAST line must be one compact JSON object below this
+
+
+def _sig(v, digits=6):
+    if isinstance(v, float) and v == v and abs(v) != float("inf"):
+        return float(f"{v:.{digits}g}")
+    return v
+
+
+def headline(full, side_file=None):
+    """The ONE line printed on stdout: the contract's keys, `roofline` and `cpu_baseline` of the dominant kernel, the parity
+    verdicts, and every other measured workload reduced to [ms_per_step, HBM fraction of its dominant kernel, parity].
+    Everything else of `full` (R-D curve arrays, per-workload prose, per-rank reports) goes to the side file."""
+    cfg = full.get("config") or {}
+    roof = full.get("roofline") or {}
+    line = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                     "scaling", "vs_baseline", "dtype", "data")}
+    line["config"] = {"workload": cfg.get("workload_short") or str(cfg.get("workload", ""))[:160],
+                      "elements_per_gpu": cfg.get("elements_per_gpu"), "lambdas": cfg.get("lambdas"),
+                      "parallelism": cfg.get("parallelism"), "launch": str(cfg.get("launch", ""))[:80],
+                      "eager_ms_per_step_right_after_warmup": _sig(cfg.get("eager_ms_per_step_right_after_warmup")),
+                      "untimed_clock_ramp_s": cfg.get("untimed_clock_ramp_s")}
+    line["roofline"] = {k: _sig(roof.get(k)) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic",
+                                                        "algorithmic_bytes_per_launch", "avg_launch_ms", "limited_by",
+                                                        "valu_issue_frac")}
+    line["roofline"]["kernel"] = str(roof.get("kernel", "")).split(" ")[0]
+    cb = full.get("cpu_baseline")
+    line["cpu_baseline"] = None if not cb else {"value": _sig(cb.get("value")), "unit": cb.get("unit"), "cores": cb.get("cores"),
+                                                "kind": cb.get("kind"), "sample": str(cb.get("sample", ""))[:200]}
+    line["parity_vs_oracle_on_sample"] = full.get("parity_vs_oracle_on_sample")
+    line["rd_lagrangian_max_rel_diff_vs_oracle"] = _sig(((full.get("rd_curve") or {}).get("vs_oracle_on_sample") or {}).get("max_rel_diff"), 3)
+    st = full.get("stages_ms") or {}
+    line["stages_ms"] = {short: _sig(v, 4) for short, v in zip(("layout", "k1t", "k1", "k2"), st.values())} if st else None
+    if full.get("allreduce"):
+        ar = full["allreduce"]
+        line["allreduce"] = {"payload_bytes": ar.get("rank_histogram_payload_bytes"), "packed_3x21": ar.get("packed_3x21"),
+                             "isolated_ms": _sig(ar.get("rank_histogram_allreduce_ms_isolated"), 4),
+                             "ms_per_step_without_collectives": _sig(ar.get("ms_per_step_without_collectives"), 4),
+                             "exposed_ms_per_step": _sig(ar.get("exposed_ms_per_step"), 4)}
+    if full.get("per_gpu"):                                  # [k1t ms, k1 ms, k2 ms, K1 HBM fraction] per rank
+        line["per_gpu"] = [[_sig(g.get("pass1_k1t_ms"), 4), _sig(g.get("pass2_k1_ms"), 4), _sig(g.get("pass2_k2_ms"), 4),
+                            _sig(g.get("k1_hbm_frac"), 3)] for g in full["per_gpu"]]
+    if full.get("workloads"):                                # name: [ms_per_step, HBM fraction of its dominant kernel, parity]
+        line["workloads"] = {k: [_sig(v.get("ms_per_step"), 4), _sig((v.get("roofline") or {}).get("frac"), 3),
+                                 v.get("parity_ok", v.get("parity_vs_oracle_on_sample"))] for k, v in full["workloads"].items()}
+    line["full_record"] = side_file
+    # never let the line outgrow the driver's parser again: shed the optional parts, largest first
+    for drop in ("workloads", "per_gpu", "allreduce", "stages_ms"):
+        if len(json.dumps(line)) < LINE_LIMIT:
+            break
+        line.pop(drop, None)
+    return line
+
+
+def emit(full, path):
+    """Write the full record to `path` (best effort) and print the compact line as the LAST line of stdout."""
+    full = compact(full)
+    side = None
+    if path:
+        try:
+            os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+            with open(path, "w") as f:
+                json.dump(full, f)
+            side = os.path.relpath(path, ROOT) if os.path.abspath(path).startswith(ROOT) else path
+        except OSError as e:
+            print(f"bench.py: could not write the full record to {path}: {e}", file=sys.stderr)
+    sys.stdout.flush()
+    print(json.dumps(headline(full, side)), flush=True)
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` started by hand (no WORLD_SIZE in the environment): this process -- which has made no GPU
+    call and has not imported torch -- starts the N ranks as child processes with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set,
+    relays rank 0's line as its own last line and exits non-zero if any rank did.  Never re-execs."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True if r == 0 else None))
+    out0, _ = procs[0].communicate()                          # rank 0 ends after the last collective: the others are done too
+    rcs = [procs[0].returncode]
+    deadline = time.time() + 120
+    for p in procs[1:]:
+        try:
+            rcs.append(p.wait(timeout=max(1.0, deadline - time.time())))
+        except subprocess.TimeoutExpired:
+            p.kill()                                           # this exact child, nothing else
+            rcs.append(p.wait())
+    lines = [l for l in (out0 or "").splitlines() if l.strip()]
+    for l in lines[:-1]:
+        print(l, file=sys.stderr)
+    if lines:
+        print(lines[-1], flush=True)
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        raise SystemExit(f"bench.py --gpus {n}: ranks failed (rank, exit code): {bad}")
+
+
 def rd_curve(ops, mu, sg, idx, tab_h, models, C, layout, lambdas, E):
     """Rate / distortion / Lagrangian per lambda of the indices `idx` on the device (vbq_rd_sums_u16, f64)."""
     import torch
@@ -392,7 +498,7 @@ def run_workload(name, args, torch, dist, dev, rank, world, steps, warmup, detai
                 graph.replay()
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
-            launch = f"one HIP graph replay per step (eager launches: {eager_ms:.3f} ms per step)"
+            launch = f"one HIP graph replay per step (eager: {eager_ms:.3f} ms)"
         except Exception as e:                     # the eager measurement above stands
             torch.cuda.synchronize()
             launch += f" (HIP graph capture failed: {type(e).__name__})"
@@ -409,7 +515,7 @@ def run_workload(name, args, torch, dist, dev, rank, world, steps, warmup, detai
         "pairs_per_step": total_E * L,
         # the same time counting both solves of every pair (pass 1 solves for the bit-length histogram only)
         "solves_per_s_counting_both_passes": 2 * total_E * L * steps / dt,
-        "roofline": {"bound": "valu", "kernel": "k_quant_fast (pass 2: corrected lengths -> rank indices)",
+        "roofline": {"bound": "hbm", "limited_by": "valu issue", "kernel": "k_quant_fast (pass 2: corrected lengths -> rank indices)",
                      "achieved": alg_bytes / (k1_ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                      "frac": alg_bytes / (k1_ms * 1e-3) / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_src,
                      "algorithmic_bytes_per_pass": alg_bytes, "launches_per_pass": k1_n,
@@ -418,8 +524,8 @@ def run_workload(name, args, torch, dist, dev, rank, world, steps, warmup, detai
                      # what bounds the kernel: share of the SIMDs' issue cycles spent on its VALU instructions (committed
                      # SQ counters); achieved / peak / frac are the HBM figures that issue rate moves
                      "valu_issue_frac": (valu or {}).get("valu_issue_frac"), "valu": valu,
-                     "bound_note": "instruction issue (VALU) bounds this kernel -- counters in `valu`; `frac` is its HBM "
-                                   "fraction on algorithmic bytes, the secondary figure",
+                     "bound_note": "HBM roofline on algorithmic bytes; what limits the kernel below it is instruction issue (VALU) "
+                                   "-- counters in `valu`",
                      # the north star's "HBM-read roofline" prices the UNFUSED per-lambda call, 8 B read per latent,
                      # i.e. a ceiling of 1.0e12 latents/s at 8 TB/s (target 60 % = 6.0e11).  The fused kernels read every element
                      # once per sweep, so this is a throughput ratio against that ceiling, not a bandwidth fraction.
@@ -430,7 +536,7 @@ def run_workload(name, args, torch, dist, dev, rank, world, steps, warmup, detai
         "stages_ms": {"layout_change": timers.total_ms("layout") / steps if C > 1 else None,
                       "pass1_k1t_solve_and_level_histogram": k1h_ms, "pass2_k1_solve": k1_ms,
                       "pass2_k2_histogram (overlapped with k1)" if k1_n > 1 else "pass2_k2_histogram": k2_ms},
-        "roofline_k1h": {"bound": "valu", "kernel": "k_level_counts_hull (pass 1, K1t: thresholds instead of a lambda loop; no per-element output)",
+        "roofline_k1h": {"bound": "hbm", "limited_by": "valu issue", "kernel": "k_level_counts_hull (pass 1, K1t: thresholds instead of a lambda loop; no per-element output)",
                          "achieved": 8.0 * E / (k1h_ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": 8.0 * E / (k1h_ms * 1e-3) / HBM_PEAK, "algorithmic_bytes_per_launch": 8 * E,
                          "avg_launch_ms": k1h_ms, "latents_per_s_kernel_only": E * L / (k1h_ms * 1e-3),
@@ -445,8 +551,10 @@ def run_workload(name, args, torch, dist, dev, rank, world, steps, warmup, detai
                                f"{', K2 overlapped in ' + str(len(build.chunks)) + ' row chunks' if len(build.chunks) > 1 else ''}) + models"
                                f"{' + RCCL all-reduce of both histograms (the model table of a step is looked up while the next step runs)' if world > 1 else ''}; one code book for all ranks "
                                f"(second moments all-reduced)" + ("; rows of one tensor split over the ranks" if strong else ""),
+                   "workload_short": f"{name} [{rows} x {C}] f32, {L}-lambda sweep, N={N_BITS}; step = two-pass entropy-model build "
+                                     f"(quantizer.py:82-150)" + ("; rows of one tensor split over the ranks" if strong else ""),
                    "elements_per_gpu": E, "lambdas": L, "parallelism": f"element-sharded x{world}",
-                   "launch": launch,
+                   "launch": launch, "untimed_clock_ramp_s": RAMP_S,
                    "clock_ramp": f"{RAMP_S} s of untimed steps ({ramp_steps} eager steps here) in front of every timed region, after the "
                                  f"{warmup} warm-up steps: the timed {steps} steps run at the clock the device sustains under this load",
                    "eager_ms_per_step_right_after_warmup": cold_ms,
@@ -602,10 +710,16 @@ def main():
     ap.add_argument("--notebook", action="store_true",
                     help="C = 1 workloads in the word-embedding notebook's arithmetic (K1n: f64 squared error, penalty "
                          "fl32(2 beta sigma^2) * length, ipynb:429-443): one K1n + K2 pass per step")
+    ap.add_argument("--full-record", default=os.environ.get("VBQ_BENCH_FULL_RECORD", os.path.join(ROOT, "bench_full.json")),
+                    help="where the full record goes (R-D curve arrays, per-workload and per-rank reports); stdout carries one "
+                         "compact line only")
     args = ap.parse_args()
     strong = args.scaling == "strong"
     if args.workload is None:
         args.workload = "synthetic_1e8" if strong else "kodak24_c256"
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:      # started by hand: be the launcher (no GPU call made so far)
+        return launch_ranks(args.gpus)
 
     import torch
     import torch.distributed as dist
@@ -613,9 +727,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit(f"--gpus {args.gpus} needs a torch.distributed.run launch with {args.gpus} ranks")
+    if args.gpus != world and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: running the {world} ranks that were launched", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm device")
     # VBQ_BENCH_ONE_DEVICE=1 (+ VBQ_BENCH_BACKEND=gloo) lets the N > 1 code path be exercised on a
@@ -637,7 +750,7 @@ def main():
 
     if args.notebook:
         out = run_notebook(args, torch, dev, cpu=not args.no_cpu_baseline)
-        print(json.dumps(compact(out)))
+        emit(out, args.full_record)
         return
 
     res = run_workload(args.workload, args, torch, dist, dev, rank, world, args.steps, args.warmup,
@@ -722,7 +835,7 @@ def main():
         if rank == 0:
             out["workloads"] = others
     if rank == 0:
-        print(json.dumps(compact(out)))
+        emit(out, args.full_record)
     if world > 1:
         dist.destroy_process_group()
     if rank == 0:
@@ -760,7 +873,7 @@ def run_call_patterns(torch, dev, steps=10, warmup=3):
     def line(ms, L, kernel, what, ok, extra=None):
         alg = E * (8 + 2 * L)
         d = {"ms_per_step": ms, "value": E * L / (ms * 1e-3), "unit": "latents/s",
-             "roofline": {"bound": "valu", "kernel": kernel, "achieved": alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+             "roofline": {"bound": "hbm", "limited_by": "valu issue", "kernel": kernel, "achieved": alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                           "frac": alg / (ms * 1e-3) / HBM_PEAK, "algorithmic_bytes_per_launch": alg, "avg_launch_ms": ms},
              "parity_vs_oracle_on_sample": ok, "workload": f"kodak24_c256: {desc}; {what}"}
         d.update(extra or {})
@@ -832,7 +945,7 @@ def run_call_patterns(torch, dev, steps=10, warmup=3):
                  for i in check)
         alg = rows1 * (8 + 2 * Lb)
         out[key] = {"ms_per_step": ms, "value": rows1 * Lb / (ms * 1e-3), "unit": "latents/s",
-                    "roofline": {"bound": "valu", "kernel": "k_quant_notebook_hull" if Lb >= 6 else "k_quant_notebook_fast",
+                    "roofline": {"bound": "hbm", "limited_by": "valu issue", "kernel": "k_quant_notebook_hull" if Lb >= 6 else "k_quant_notebook_fast",
                                  "achieved": alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": alg / (ms * 1e-3) / HBM_PEAK,
                                  "algorithmic_bytes_per_launch": alg, "avg_launch_ms": ms},
                     "parity_vs_oracle_on_sample": bool(ok),
@@ -884,7 +997,7 @@ def run_notebook(args, torch, dev, workload=None, steps=None, warmup=None, cpu=T
            "config": {"workload": f"{name}: {desc}; {L}-point beta sweep exp(linspace(log 0.01, log 1e5, {L})), notebook arithmetic "
                                   f"(K1nt, f64 squared error, ipynb:429-443) + K2 histogram (empirical_entropy, ipynb:452-455); "
                                   f"one solve per (element, beta) per step", "elements_per_gpu": rows, "lambdas": L},
-           "roofline": {"bound": "valu", "kernel": "k_quant_notebook_hull", "achieved": alg / (k1_ms * 1e-3) / 1e9,
+           "roofline": {"bound": "hbm", "limited_by": "valu issue", "kernel": "k_quant_notebook_hull", "achieved": alg / (k1_ms * 1e-3) / 1e9,
                         "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": alg / (k1_ms * 1e-3) / HBM_PEAK, "traffic": None,
                         "algorithmic_bytes_per_launch": alg, "avg_launch_ms": k1_ms}}
     # the notebook's own brute force over all 2047 code points (C oracle, OpenMP), a bounded sample

@@ -280,21 +280,42 @@ def test_cabi_communicator_single_rank(tmp_path):
     _run_cabi_comm(1, tmp_path)
 
 
-@pytest.mark.timeout(600)
-def _run_bench_two_ranks(extra, port_off=0):
+def _run_bench_two_ranks(extra, tmp_path, launcher="torchrun"):
+    """-> (the compact line the driver parses, the full record from the side file)."""
     import json
+    import socket
     import subprocess
     env = dict(os.environ, VBQ_BENCH_ONE_DEVICE="1", VBQ_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(29700 + (os.getpid() + port_off) % 100), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
-           "--warmup", "1", "--no-other-workloads"] + extra
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    full = str(tmp_path / "bench_full.json")
+    tail = ["--gpus", "2", "--steps", "3", "--warmup", "1", "--no-other-workloads", "--full-record", full] + extra
+    if launcher == "torchrun":                    # as the driver launches N > 1
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.join(ROOT, "bench.py")] + tail
+    else:                                         # plain `python bench.py --gpus 2`: bench.py starts its own ranks
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + tail
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1
-    return json.loads(lines[0])
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len([l for l in lines if l.startswith("{")]) == 1 and lines[-1].startswith("{")
+    assert len(lines[-1]) < 4096                  # what the driver's parser takes
+    return json.loads(lines[-1]), json.load(open(full))
 
 
+def _check_compact_line(line, d):
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline", "parity_vs_oracle_on_sample"):
+        assert k in line, k
+    assert line["value"] == d["value"] and line["ms_per_step"] == d["ms_per_step"] and line["n_gpus"] == d["n_gpus"]
+    assert line["roofline"]["bound"] == "hbm" and 0 < line["roofline"]["frac"] < 1
+    assert line["parity_vs_oracle_on_sample"] is True and len(line["per_gpu"]) == 2
+
+
+@pytest.mark.timeout(900)
 def test_bench_two_ranks_code_path(tmp_path):
     """bench.py's N > 1 path end to end as the driver launches it (torch.distributed.run, 2 ranks), on one GPU with gloo
     as the transport (VBQ_BENCH_ONE_DEVICE / VBQ_BENCH_BACKEND: testing switches): one JSON line from rank 0 with the
@@ -303,7 +324,8 @@ def test_bench_two_ranks_code_path(tmp_path):
     sum of the ranks' single-launch histograms, the R-D curve against the oracle's, every rank's own kernel report."""
     if not torch.cuda.is_available():
         pytest.fail("gpu-marked test run without a ROCm device")
-    d = _run_bench_two_ranks(["--workload", "kodak24_c32"])
+    line, d = _run_bench_two_ranks(["--workload", "kodak24_c32"], tmp_path)
+    _check_compact_line(line, d)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     ar = d["allreduce"]
     assert ar["packed_3x21"] is True and ar["rank_histogram_payload_bytes"] == ((32 * 32 * 2047 + 2) // 3 + 1) * 8
@@ -322,12 +344,25 @@ def test_bench_two_ranks_code_path(tmp_path):
     assert len(d["rd_curve"]["lagrangian_per_latent"]) == 32 and d["rd_curve"]["vs_oracle_on_sample"]["max_rel_diff"] <= 1e-5
 
 
-def test_bench_two_ranks_strong_scaling_splits_one_tensor():
+@pytest.mark.timeout(900)
+def test_bench_two_ranks_self_launched(tmp_path):
+    """Plain `python bench.py --gpus 2` (no torch.distributed.run around it): the parent, which makes no GPU call, starts
+    the two ranks itself and relays rank 0's compact line as its last line."""
+    if not torch.cuda.is_available():
+        pytest.fail("gpu-marked test run without a ROCm device")
+    line, d = _run_bench_two_ranks(["--workload", "kodak24_c32"], tmp_path, launcher="self")
+    _check_compact_line(line, d)
+    assert d["n_gpus"] == 2 and d["pairs_per_step"] == 2 * 36864 * 32 * 32
+    assert [f["ok"] for f in d["parity"]["ranks"]] == [True, True]
+
+
+@pytest.mark.timeout(900)
+def test_bench_two_ranks_strong_scaling_splits_one_tensor(tmp_path):
     """--scaling strong: the rows of ONE tensor are split over the ranks (BASELINE configs[3]'s curve), the pairs of the
     whole tensor are counted once, and the global histograms hold exactly that tensor."""
     if not torch.cuda.is_available():
         pytest.fail("gpu-marked test run without a ROCm device")
-    d = _run_bench_two_ranks(["--workload", "kodak24_c32", "--scaling", "strong"], port_off=37)
+    _, d = _run_bench_two_ranks(["--workload", "kodak24_c32", "--scaling", "strong"], tmp_path)
     assert d["n_gpus"] == 2 and d["scaling"] == "strong"
     assert d["config"]["elements_per_gpu"] == 18432 * 32 and d["pairs_per_step"] == 36864 * 32 * 32
     assert d["parity_vs_oracle_on_sample"] is True and d["parity"]["counts_total"] is True

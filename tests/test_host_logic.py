@@ -1,10 +1,14 @@
 """Host-side logic that needs no GPU: table index arithmetic, entropy-model arithmetic,
 quantizer state, argument validation and the refusal to run without a device."""
+import os
 import pickle
+import sys
 
 import numpy as np
 import pytest
 import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 from oracle import vbq_oracle as O
 from vbq_amd import ChannelwisePriorCDFQuantizer, VBQError, entropy, ops, priors, tables, utils
@@ -180,3 +184,57 @@ def test_quantize_facade_table_cache_keys():
     k0 = api._table_key(t)
     t[0, 0] = 1.0
     assert api._table_key(t) != k0
+
+
+def test_bench_headline_line_is_compact_and_complete(tmp_path, capsys):
+    """The line the driver parses: built from a canned full record (last round's, plus an 8-rank per-GPU report and the
+    all-reduce block of an N > 1 run), it must stay below 4 KB, be the LAST line of stdout, and carry the contract's keys with
+    `roofline` and `cpu_baseline`; the full record goes to the side file untouched."""
+    import json
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", "r3_bench_full.json")))
+    full["n_gpus"] = 8
+    full["per_gpu"] = [{"rank": r, "elements": 9437184, "pass1_k1t_ms": 0.12345678, "pass2_k1_ms": 0.3303153, "pass2_k2_ms": 0.1513,
+                        "layout_change_ms": 0.032, "k1_hbm_frac": 0.257132, "k1t_hbm_frac": 0.07, "k2_hbm_frac": 0.49,
+                        "pairs_per_s_kernels_only": 4.9e11} for r in range(8)]
+    full["allreduce"] = {"rank_histogram_payload_bytes": 44717064, "level_histogram_payload_bytes": 720896, "packed_3x21": True,
+                         "counter_dtype": "int32", "rank_histogram_allreduce_ms_isolated": 0.6123456, "ms_per_step_without_collectives": 0.65,
+                         "exposed_ms_per_step": 0.0123, "overlap": "x" * 300}
+    side = str(tmp_path / "sub" / "full.json")
+    bench.emit(full, side)
+    out = capsys.readouterr().out.splitlines()
+    assert len(out) == 1 and len(out[0]) < bench.LINE_LIMIT
+    line = json.loads(out[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline", "parity_vs_oracle_on_sample", "rd_lagrangian_max_rel_diff_vs_oracle",
+              "workloads", "per_gpu", "allreduce", "full_record"):
+        assert k in line, k
+    assert line["value"] == full["value"] and line["ms_per_step"] == full["ms_per_step"]
+    for k in ("workload", "elements_per_gpu", "lambdas", "launch", "eager_ms_per_step_right_after_warmup"):
+        assert k in line["config"], k
+    for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_ms", "valu_issue_frac"):
+        assert k in line["roofline"], k
+    assert line["roofline"]["kernel"] == "k_quant_fast" and line["roofline"]["frac"] == pytest.approx(full["roofline"]["frac"], rel=1e-5)
+    for k in ("value", "unit", "cores", "kind"):
+        assert k in line["cpu_baseline"], k
+    assert all(len(v) == 3 for v in line["workloads"].values()) and len(line["workloads"]) == len(full["workloads"])
+    assert len(line["per_gpu"]) == 8 and all(len(g) == 4 for g in line["per_gpu"])
+    assert json.load(open(side))["rd_curve"]["lambda"] == pytest.approx(full["rd_curve"]["lambda"], rel=1e-6)
+    # a record that would still be too long sheds its optional parts instead of outgrowing the parser
+    full["workloads"] = {f"w{i}_" + "x" * 40: v for i, v in enumerate(list(full["workloads"].values()) * 8)}
+    l2 = bench.headline(full, None)
+    assert len(json.dumps(l2)) < bench.LINE_LIMIT and "workloads" not in l2 and "roofline" in l2 and "cpu_baseline" in l2
+
+
+def test_bench_self_launch_propagates_rank_failure():
+    """`python bench.py --gpus 2` without WORLD_SIZE: the parent starts the ranks itself.  Without a ROCm device every rank
+    exits with an error -- the parent must report it and exit non-zero (never hang, never print a JSON line)."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["HIP_VISIBLE_DEVICES"] = ""            # also on a GPU box: the ranks must not find a device
+    env["CUDA_VISIBLE_DEVICES"] = ""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode != 0
+    assert "ranks failed" in r.stderr and "needs a ROCm device" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
