@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define VBQ_ABI_VERSION 3
+#define VBQ_ABI_VERSION 4
 
 enum {
     VBQ_OK = 0,
@@ -313,6 +313,42 @@ int vbq_transpose_f32(const float *d_in, int64_t n_rows, int64_t n_cols, float *
  * quantizer.py:186-188); with 4, Z_hat / num_bits planes.  n_batch <= 65535. */
 int vbq_transpose_planes(const void *d_in, int64_t n_batch, int64_t n_rows, int64_t n_cols, int32_t elem_bytes,
                          void *d_out, void *stream);
+
+/* ----------------------------------------------------------------------------------
+ * The per-image call of the evaluation loop: ChannelwisePriorCDFQuantizer.compress_latents
+ * (quantizer.py:190-240, called once per image by utils.py:542-554) as ONE C call =
+ * three launches (planes, solve, fused lookups).  The three pieces are entry points of
+ * their own as well.
+ *
+ *   vbq_prep_planes_f32     channel-last latents [n_rows][n_ch] -> channel-major planes [n_ch][n_rows]
+ *                           (the tf.transpose of quantizer.py:163-164,223), means and spreads in one launch;
+ *                           spread_is_variance != 0: the spreads are exp(logvar) and sigma = sqrt(.) is taken
+ *                           on the way (quantizer.py:197,202 `tf.exp(posterior_logvars) ** 0.5`; IEEE sqrt).
+ *   vbq_gather_latents_u16  ONE pass over rank indices in planes [n_lambda][n_ch][n_rows] writing, channel-last
+ *                           [n_lambda][n_rows][n_ch] (any subset; NULL skips an output):
+ *                             d_out_zhat      f32  d_table_sorted[c][q]                      quantizer.py:224-225
+ *                             d_out_raw_bits  the bit length n(q) = N - ctz(q + 1) of the winner as int32 when
+ *                                             d_level_len is NULL (quantizer.py:167-169), else f32
+ *                                             d_level_len[l][c][n(q)] = "n + overhead"        quantizer.py:171-175
+ *                             d_out_num_bits  f32  d_models[l][c][q] (entropy_models, by rank) quantizer.py:226-228
+ *                             d_out_idx       u16  q itself (the index planes transposed)
+ *   vbq_compress_latents_f32   prep -> vbq_quantize_f32 on planes (raw lengths when d_level_len is NULL) ->
+ *                           gather.  d_spread_bc holds sigma, or exp(logvar) with spread_is_variance != 0.
+ *                           Workspace: vbq_compress_latents_workspace_bytes() bytes of device memory, 256-byte
+ *                           aligned (the planes, the index planes and the solve's own workspace live there).
+ * ---------------------------------------------------------------------------------- */
+int vbq_prep_planes_f32(const float *d_means_bc, const float *d_spread_bc, int32_t spread_is_variance, int64_t n_rows,
+                        int32_t n_ch, float *d_mu_cb, float *d_sigma_cb, void *stream);
+int vbq_gather_latents_u16(const uint16_t *d_idx_planes, int64_t n_rows, int32_t n_ch, int32_t n_lambda, int32_t N,
+                           const float *d_table_sorted, const float *d_level_len, const float *d_models,
+                           float *d_out_zhat, void *d_out_raw_bits, float *d_out_num_bits, uint16_t *d_out_idx,
+                           void *stream);
+size_t vbq_compress_latents_workspace_bytes(int64_t n_rows, int32_t n_ch, int32_t n_lambda, int32_t N);
+int vbq_compress_latents_f32(const float *d_means_bc, const float *d_spread_bc, int32_t spread_is_variance,
+                             int64_t n_rows, int32_t n_ch, const float *d_table_lm, const float *d_table_sorted,
+                             const float *d_level_len, const float *d_models, const double *h_lambdas,
+                             int32_t n_lambda, int32_t N, float *d_out_zhat, void *d_out_raw_bits,
+                             float *d_out_num_bits, void *d_workspace, size_t workspace_bytes, void *stream);
 
 /* ----------------------------------------------------------------------------------
  * K4  BMSHJ2018 prior (learned_prior.py).  Parameters are the EFFECTIVE ones --

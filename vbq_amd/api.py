@@ -9,7 +9,7 @@ import torch
 
 from . import ops
 from ._lib import VBQError
-from .tables import dyadic_xi, level_major_to_sorted, table_size
+from .tables import dyadic_xi, level_major_to_sorted, level_of_rank, rank_of_slot, table_size
 
 
 def gaussian_table(scale, N: int = 10, loc=0.0) -> np.ndarray:
@@ -21,30 +21,44 @@ def gaussian_table(scale, N: int = 10, loc=0.0) -> np.ndarray:
     return norm.ppf(dyadic_xi(N)[None, :], loc=loc[:, None], scale=scale[:, None]).astype(np.float32)
 
 
-# Tables that already passed the monotonicity check (and, for host tables, their device copies): a sweep calls quantize()
-# many times with ONE table, and the check costs a device-to-host copy of it.  Keyed by the object's identity and, for
-# tensors, its storage pointer and version counter, so an in-place edit or a new table is checked again.
+# Tables that already passed the monotonicity check, with their device copies (level-major and rank order): a sweep calls
+# quantize() many times with ONE table, and the check costs a device-to-host copy of it.  A tensor is keyed by its identity,
+# storage pointer and version counter, so an in-place edit or a new tensor is checked again.  A NumPy array has no version
+# counter -- an edit in place is invisible to any identity key -- so it is keyed by a hash of its CONTENT: the same bytes
+# give the same device copy, anything else is copied and checked afresh.
 _CHECKED = {}
+
+
+def _content_hash(a: np.ndarray):
+    a = np.ascontiguousarray(a)
+    try:
+        import xxhash
+        return xxhash.xxh3_128_hexdigest(a.view(np.uint8).reshape(-1).data)
+    except ImportError:                                      # slower, same guarantee
+        import hashlib
+        return hashlib.blake2b(a.view(np.uint8).reshape(-1).data, digest_size=16).hexdigest()
 
 
 def _table_key(table):
     if isinstance(table, torch.Tensor):
         return ("t", id(table), table.data_ptr(), table._version, tuple(table.shape), str(table.device))
-    return ("n", id(table), table.__array_interface__["data"][0], tuple(table.shape))
+    return ("n", str(table.dtype), tuple(table.shape), _content_hash(table))
 
 
-def _device_table(table, C: int, N: int, dev, validate: bool) -> torch.Tensor:
-    """Level-major f32 [C, T] on `dev`; raises ValueError unless every channel is non-decreasing in xi (tf.searchsorted is
-    undefined otherwise, quantizer.py:135).  Checked once per table object."""
+def _device_table(table, C: int, N: int, dev, validate: bool):
+    """(level-major, rank-order) f32 [C, T] copies on `dev`; raises ValueError unless every channel is non-decreasing in xi
+    (tf.searchsorted is undefined otherwise, quantizer.py:135).  Checked once per table tensor / table content."""
     T = table_size(N)
     if not isinstance(table, torch.Tensor):
         table = np.asarray(table)
     key = _table_key(table)
     hit = _CHECKED.get(key)
-    if hit is not None and hit[0]() is table and hit[2] == (C, N, str(dev)):
+    if hit is not None and (hit[0] is None or hit[0]() is table) and hit[2] == (C, N, str(dev)):
         return hit[1]
     tab_t = (torch.from_numpy(np.ascontiguousarray(table, dtype=np.float32)) if not isinstance(table, torch.Tensor) else table)
     tab_t = tab_t.to(dev, torch.float32).reshape(C, T).contiguous()
+    slot_of_rank = torch.from_numpy(np.argsort(rank_of_slot(N))).to(dev)
+    pair = (tab_t, tab_t[:, slot_of_rank].contiguous())      # rank order == sorted order for a monotone table
     if validate:
         host = table if not isinstance(table, torch.Tensor) else tab_t.cpu().numpy()
         host = np.asarray(host, dtype=np.float32).reshape(C, T)
@@ -52,16 +66,16 @@ def _device_table(table, C: int, N: int, dev, validate: bool) -> torch.Tensor:
             raise ValueError("table is not monotone in xi")
         if len(_CHECKED) > 64:
             _CHECKED.clear()
-        try:
-            _CHECKED[key] = (weakref.ref(table), tab_t, (C, N, str(dev)))
-        except TypeError:                                   # objects without weak references are checked every time
-            pass
-    return tab_t
+        if isinstance(table, torch.Tensor):
+            _CHECKED[key] = (weakref.ref(table), pair, (C, N, str(dev)))
+        else:
+            _CHECKED[key] = (None, pair, (C, N, str(dev)))    # content-keyed: whoever holds these bytes gets this copy
+    return pair
 
 
 def quantize(mu, sigma, lmbda: Union[float, Sequence[float]], *, table=None, prior=None, N: int = 10,
-             lengths=None, layout: str = "bc", return_values: bool = False, return_bits: bool = False,
-             validate: bool = True):
+             lengths=None, layout: str = "bc", out_layout: str = "same", return_values: bool = False,
+             return_bits: bool = False, return_indices: bool = True, validate: bool = True):
     """argmin over the 2^(N+1)-1 code points of  (z-mu)^2/(2 sigma^2) + lambda * R(z)  for every
     element and every lambda, with the arithmetic and tie rules of the reference
     (quantizer.py:156-188 + utils.py:363-423).
@@ -72,19 +86,30 @@ def quantize(mu, sigma, lmbda: Union[float, Sequence[float]], *, table=None, pri
     table     : level-major f32 [C, T] code points (ChannelwisePriorCDFQuantizer.all_code_points);
                 or `prior` with .inverse_cdf(xi[T, C]) from which the table is built.
     lengths   : optional f32 [L, C, N+1] code length per bit level (default: the level itself).
-    validate  : check (once per table object) that the table is monotone in xi; False skips the check.
-    Returns rank indices (uint16; position in the sorted table) shaped like the input with the lambda axis in front and,
-    if asked, the code-point values / code lengths (f32).  Torch in -> device tensors out; NumPy in -> NumPy out.
+    out_layout: 'same' (results shaped like the input) or 'planes': channel-major [L, C, rows] results whatever the input
+                layout -- what the kernels write; a caller that goes on to a histogram, a lookup or the entropy coder (all of
+                which take planes) saves the transpose back, half the time of a channel-last sweep.
+    return_indices=False with return_values / return_bits: only those are produced (and returned).
+    validate  : check (once per table tensor / table content) that the table is monotone in xi; False skips the check.
+    Returns rank indices (uint16; position in the sorted table) with the lambda axis in front and, if asked, the code-point
+    values / code lengths (f32).  Torch in -> device tensors out; NumPy in -> NumPy out.
 
-    Channel-last input takes the plane kernels: two input transposes (vbq_transpose_f32), the solve on [C, rows] planes
-    (K1e for raw-length sweeps of 16-32 lambdas, K1 otherwise), and one batched transpose of the results back into the
-    caller's layout (vbq_transpose_planes) -- 1.6x faster than the channel-last kernel it replaces."""
+    Channel-last input takes the plane kernels: one launch that turns means and sigmas into [C, rows] planes
+    (vbq_prep_planes_f32), the solve on planes (K1e for raw-length sweeps of 16-32 lambdas, K1p for one or two lambdas, K1
+    otherwise; indices only), then ONE pass over the index planes that writes whatever was asked for in the caller's layout
+    (vbq_transpose_planes for indices alone; vbq_gather_latents_u16 for values / lengths, which are table lookups on the
+    indices, with the indices transposed in the same pass).  Peak device memory of that route: inputs + their planes +
+    index planes + results."""
     scalar = np.isscalar(lmbda)
     lambdas = [float(lmbda)] if scalar else [float(v) for v in lmbda]
     if not torch.cuda.is_available():
         raise VBQError("no ROCm device visible: vbq_amd.quantize has no CPU implementation")
     if layout not in ("bc", "cb"):
         raise ValueError(f"layout must be 'bc' or 'cb', got {layout!r}")
+    if out_layout not in ("same", "planes"):
+        raise ValueError(f"out_layout must be 'same' or 'planes', got {out_layout!r}")
+    if not (return_indices or return_values or return_bits):
+        raise ValueError("nothing to return")
     dev = torch.device("cuda", torch.cuda.current_device())
     was_np = not isinstance(mu, torch.Tensor)
     mu_t = (torch.from_numpy(np.ascontiguousarray(mu)) if was_np else mu).to(dev, torch.float32)
@@ -99,21 +124,46 @@ def quantize(mu, sigma, lmbda: Union[float, Sequence[float]], *, table=None, pri
         pts = prior.inverse_cdf(xi)
         pts = pts.cpu().numpy() if isinstance(pts, torch.Tensor) else np.asarray(pts)
         table = np.ascontiguousarray(pts.astype(np.float32).T)
-    tab_t = _device_table(table, C, N, dev, validate)
+    tab_t, srt_t = _device_table(table, C, N, dev, validate)
     len_t = None
     if lengths is not None:
         len_t = (torch.from_numpy(np.ascontiguousarray(lengths)) if not isinstance(lengths, torch.Tensor) else lengths)
         len_t = len_t.to(dev, torch.float32)
-    planes = layout == "bc" and mu_t.dim() == 2 and C > 1 and mu_t.shape[0] > 0
-    if planes:
-        res = ops.quantize(ops.transpose(mu_t), ops.transpose(sg_t), tab_t, lambdas, N=N, level_len=len_t, layout="cb",
-                           want_zhat=return_values, want_bits=return_bits)
-        res = res if isinstance(res, tuple) else (res,)
-        res = tuple(ops.transpose_planes(r) for r in res)          # [L, C, rows] -> [L, rows, C]
+    L = len(lambdas)
+    channel_last = layout == "bc" and mu_t.dim() == 2 and C > 1 and mu_t.shape[0] > 0
+    if channel_last:
+        mu_p, sg_p = ops.prep_planes(mu_t, sg_t)
+    elif mu_t.dim() == 2 and layout == "bc":                   # C == 1 (or no rows): planes and channel-last coincide
+        mu_p, sg_p = mu_t.reshape(C, -1), sg_t.reshape(C, -1)
     else:
-        res = ops.quantize(mu_t, sg_t, tab_t, lambdas, N=N, level_len=len_t, layout=layout,
-                           want_zhat=return_values, want_bits=return_bits)
-        res = res if isinstance(res, tuple) else (res,)
+        mu_p, sg_p = mu_t, sg_t
+    idx_p = ops.quantize(mu_p, sg_p, tab_t, lambdas, N=N, level_len=len_t, layout="cb")        # [L, C, rows] / [L, n]
+    to_caller = channel_last and out_layout == "same"
+    if to_caller and (return_values or return_bits):
+        z, b, _, qi = ops.gather_latents(idx_p, N=N, table_sorted=srt_t, level_len=len_t, want_zhat=return_values,
+                                         want_raw_bits=return_bits, want_idx=return_indices)
+        if b is not None and b.dtype != torch.float32:
+            b = b.to(torch.float32)
+        res = tuple(r for r in (qi, z, b) if r is not None)
+    elif to_caller:
+        res = (ops.transpose_planes(idx_p),)                    # [L, C, rows] -> [L, rows, C]
+    else:
+        shape = (L,) + tuple(mu_p.shape)
+        if out_layout == "same":
+            shape = (L,) + tuple(mu_t.shape)
+        elif mu_t.dim() == 2 and layout == "bc":
+            shape = (L, C, mu_t.shape[0])
+        planes3 = idx_p.reshape(L, C, -1)
+        res = (idx_p.reshape(shape),) if return_indices else ()
+        if return_values:
+            res += (ops.gather(planes3, srt_t, C, N=N, layout="cb").reshape(shape),)
+        if return_bits:
+            lev = torch.from_numpy(level_of_rank(N)).to(dev)
+            if len_t is None:
+                lt = lev.to(torch.float32).expand(C, -1).contiguous()                        # [C, T]: level of every rank
+            else:
+                lt = torch.gather(len_t, 2, lev.expand(L, C, -1)).contiguous()               # [L, C, T]: length of every rank
+            res += (ops.gather(planes3, lt, C, N=N, layout="cb").reshape(shape),)
     if scalar:
         res = tuple(r[0] for r in res)
     if was_np:

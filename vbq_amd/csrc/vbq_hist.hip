@@ -426,7 +426,8 @@ k_gather_transpose(const uint16_t *__restrict__ idx, long in_rows, long in_cols,
     const uint16_t *src = idx + (long)l * E;
     float *dst = out + (long)l * E;
     const float *tl = tab + (per_lambda ? (long)l * C * T : 0);
-    const long r0 = (long)blockIdx.y * 32, c0 = (long)blockIdx.x * 32;
+    const long ctiles = (in_cols + 31) / 32;                         // tiles numbered along blockIdx.x, columns fastest
+    const long r0 = ((long)blockIdx.x / ctiles) * 32, c0 = ((long)blockIdx.x % ctiles) * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -447,7 +448,8 @@ k_gather_transpose(const uint16_t *__restrict__ idx, long in_rows, long in_cols,
 __global__ void __launch_bounds__(256)
 k_transpose(const float *__restrict__ in, long rows, long cols, float *__restrict__ out) {
     __shared__ float tile[64][65];
-    const long r0 = (long)blockIdx.y * 64, c0 = (long)blockIdx.x * 64;
+    const long ctiles = (cols + 63) / 64;        // tiles numbered along blockIdx.x (columns fastest): no 65535-tile limit on rows
+    const long r0 = ((long)blockIdx.x / ctiles) * 64, c0 = ((long)blockIdx.x % ctiles) * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;          // 64 x 4
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
@@ -466,7 +468,8 @@ k_transpose(const float *__restrict__ in, long rows, long cols, float *__restric
 __global__ void __launch_bounds__(256)
 k_transpose_v4(const float *__restrict__ in, long rows, long cols, float *__restrict__ out) {
     __shared__ float tile[64][65];
-    const long r0 = (long)blockIdx.y * 64, c0 = (long)blockIdx.x * 64;
+    const long ctiles = (cols + 63) / 64;
+    const long r0 = ((long)blockIdx.x / ctiles) * 64, c0 = ((long)blockIdx.x % ctiles) * 64;
     if (r0 + 64 <= rows && c0 + 64 <= cols) {
         // whole tile (workgroup-uniform): the four loads of a thread go out together, then the LDS writes -- with the bounds
         // test around every access each load was waited for before the next one was issued
@@ -524,9 +527,10 @@ k_transpose_batched_vec(const T *__restrict__ in, long rows, long cols, T *__res
     constexpr int PER = 64 * VPR / 256;                      // vectors per thread
     struct alignas(16) Vec { T e[V]; };
     __shared__ T tile[64][64 + 2];
-    in += (long)blockIdx.z * rows * cols;
-    out += (long)blockIdx.z * rows * cols;
-    const long r0 = (long)blockIdx.y * 64, c0 = (long)blockIdx.x * 64;
+    in += (long)blockIdx.y * rows * cols;
+    out += (long)blockIdx.y * rows * cols;
+    const long ctiles = (cols + 63) / 64;
+    const long r0 = ((long)blockIdx.x / ctiles) * 64, c0 = ((long)blockIdx.x % ctiles) * 64;
     if (r0 + 64 <= rows && c0 + 64 <= cols) {                  // whole tile: loads together, then LDS (see k_transpose_v4)
         Vec v[PER];
 #pragma unroll
@@ -582,9 +586,10 @@ template <typename T>
 __global__ void __launch_bounds__(256)
 k_transpose_batched(const T *__restrict__ in, long rows, long cols, T *__restrict__ out) {
     __shared__ T tile[64][65];
-    in += (long)blockIdx.z * rows * cols;
-    out += (long)blockIdx.z * rows * cols;
-    const long r0 = (long)blockIdx.y * 64, c0 = (long)blockIdx.x * 64;
+    in += (long)blockIdx.y * rows * cols;
+    out += (long)blockIdx.y * rows * cols;
+    const long ctiles = (cols + 63) / 64;
+    const long r0 = ((long)blockIdx.x / ctiles) * 64, c0 = ((long)blockIdx.x % ctiles) * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;          // 64 x 4
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
@@ -604,7 +609,7 @@ int launch_transpose_batched(const T *in, int64_t batch, int64_t rows, int64_t c
     constexpr int V = 16 / sizeof(T);
     const bool vec = rows % V == 0 && cols % V == 0 && ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) == 0 &&
                      (rows * cols * (int64_t)sizeof(T)) % 16 == 0;
-    const dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((rows + 63) / 64), (unsigned)batch);
+    const dim3 grid((unsigned)(((cols + 63) / 64) * ((rows + 63) / 64)), (unsigned)batch);      // tiles on x, planes on y
     if (vec)
         hipLaunchKernelGGL((k_transpose_batched_vec<T>), grid, dim3(256), 0, st, in, (long)rows, (long)cols, out);
     else
@@ -1099,10 +1104,10 @@ extern "C" int vbq_gather_f32(const uint16_t *d_idx, int64_t n_rows, int32_t n_c
     if (n_ch > 1 && layout != out_layout) {
         const int64_t in_rows = layout == VBQ_LAYOUT_CB ? n_ch : n_rows;
         const int64_t in_cols = layout == VBQ_LAYOUT_CB ? n_rows : n_ch;
-        VBQ_REQUIRE(n_lambda <= 65535 && (in_rows + 31) / 32 <= 65535, VBQ_ERR_UNSUPPORTED,
+        const int64_t tiles = ((in_cols + 31) / 32) * ((in_rows + 31) / 32);
+        VBQ_REQUIRE(n_lambda <= 65535 && tiles <= 0x7fffffffll, VBQ_ERR_UNSUPPORTED,
                     "vbq_gather_f32: grid too large for the transposing form");
-        hipLaunchKernelGGL(k_gather_transpose, dim3((unsigned)((in_cols + 31) / 32), (unsigned)((in_rows + 31) / 32),
-                                                    (unsigned)n_lambda),
+        hipLaunchKernelGGL(k_gather_transpose, dim3((unsigned)tiles, 1, (unsigned)n_lambda),
                            dim3(256), 0, reinterpret_cast<hipStream_t>(stream), d_idx, (long)in_rows, (long)in_cols,
                            (int)layout, (long)E, (int)n_ch, table_size(N), d_tab, (int)tab_per_lambda, d_out);
         VBQ_CHECK_LAUNCH("gather_transpose");
@@ -1146,8 +1151,8 @@ extern "C" int vbq_transpose_planes(const void *d_in, int64_t n_batch, int64_t n
     VBQ_REQUIRE(elem_bytes == 2 || elem_bytes == 4, VBQ_ERR_INVALID_ARGUMENT, "vbq_transpose_planes: elem_bytes %d (2 or 4)", elem_bytes);
     if (n_batch == 0 || n_rows == 0 || n_cols == 0) return VBQ_OK;
     VBQ_REQUIRE(d_in && d_out && d_in != d_out, VBQ_ERR_INVALID_ARGUMENT, "vbq_transpose_planes: null or aliased pointers");
-    VBQ_REQUIRE((n_rows + 63) / 64 <= 65535 && n_batch <= 65535, VBQ_ERR_UNSUPPORTED,
-                "vbq_transpose_planes: more than 4.19e6 rows or 65535 planes");
+    VBQ_REQUIRE(((n_rows + 63) / 64) * ((n_cols + 63) / 64) <= 0x7fffffffll && n_batch <= 65535, VBQ_ERR_UNSUPPORTED,
+                "vbq_transpose_planes: more than 2^31 - 1 tiles of 64 x 64 per plane or more than 65535 planes");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (elem_bytes == 2)
         return launch_transpose_batched<uint16_t>(static_cast<const uint16_t *>(d_in), n_batch, n_rows, n_cols,
@@ -1161,9 +1166,10 @@ extern "C" int vbq_transpose_f32(const float *d_in, int64_t n_rows, int64_t n_co
     VBQ_REQUIRE(n_rows >= 0 && n_cols >= 0, VBQ_ERR_INVALID_ARGUMENT, "vbq_transpose_f32: bad sizes");
     if (n_rows == 0 || n_cols == 0) return VBQ_OK;
     VBQ_REQUIRE(d_in && d_out && d_in != d_out, VBQ_ERR_INVALID_ARGUMENT, "vbq_transpose_f32: null or aliased pointers");
-    VBQ_REQUIRE((n_rows + 63) / 64 <= 65535, VBQ_ERR_UNSUPPORTED, "vbq_transpose_f32: more than 4.19e6 rows");
+    const int64_t tiles = ((n_rows + 63) / 64) * ((n_cols + 63) / 64);
+    VBQ_REQUIRE(tiles <= 0x7fffffffll, VBQ_ERR_UNSUPPORTED, "vbq_transpose_f32: more than 2^31 - 1 tiles of 64 x 64");
     const bool v4 = n_rows % 4 == 0 && n_cols % 4 == 0 && ((reinterpret_cast<uintptr_t>(d_in) | reinterpret_cast<uintptr_t>(d_out)) & 15) == 0;
-    const dim3 grid((unsigned)((n_cols + 63) / 64), (unsigned)((n_rows + 63) / 64));
+    const dim3 grid((unsigned)tiles);
     if (v4)
         hipLaunchKernelGGL(k_transpose_v4, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), d_in, (long)n_rows,
                            (long)n_cols, d_out);

@@ -1,0 +1,221 @@
+// The per-image call of the reference's evaluation loop -- ChannelwisePriorCDFQuantizer.compress_latents,
+// img-compression/quantizer.py:190-240, called once per image by utils.py:542-554 -- as ONE C call and three launches:
+//
+//   k_prep_planes       channel-last means / spreads [B][C] -> channel-major planes [C][B] (quantizer.py:163-164,223),
+//                       with sigma = sqrt(variance) folded in when the caller hands exp(logvar) (quantizer.py:197,202:
+//                       `tf.exp(posterior_logvars) ** 0.5`; sqrt is correctly rounded, so it is the same number)
+//   K1 / K1e / K1p      the solve on planes (vbq_quantize_f32)
+//   k_gather_latents    ONE pass over the rank indices [L][C][B]: Z_hat = sorted table[c][q]  (quantizer.py:224-225),
+//                       raw_num_bits = level(q) or level_len[l][c][level(q)] (:171-175,186-188), num_bits =
+//                       entropy_model[l][c][q] (:226-228), all written channel-last [L][B][C] (the np.reshape of :237),
+//                       optionally the indices themselves channel-last.
+//
+// The level of rank index q is N - ctz(q + 1) (slot (n, i) <-> rank (2i + 1) 2^(N-n) - 1), so no per-rank length table is
+// built or read.
+#include "vbq_common.h"
+
+namespace vbq {
+namespace {
+
+// ---------------------------------------------------------------------------- planes from channel-last latents
+// in [rows][cols] -> out [cols][rows], 64 x 64 tiles through LDS; blockIdx.y = 0: means, 1: spreads (sqrt when asked).
+__global__ void __launch_bounds__(256)
+k_prep_planes(const float *__restrict__ in0, const float *__restrict__ in1, long rows, long cols, float *__restrict__ out0,
+              float *__restrict__ out1, int sqrt1, int v4) {
+    __shared__ float tile[64][65];
+    const bool second = blockIdx.y == 1;
+    const float *in = second ? in1 : in0;
+    float *out = second ? out1 : out0;
+    const bool root = second && sqrt1;
+    const long ctiles = (cols + 63) / 64;
+    const long r0 = ((long)blockIdx.x / ctiles) * 64, c0 = ((long)blockIdx.x % ctiles) * 64;
+    if (v4 && r0 + 64 <= rows && c0 + 64 <= cols) {
+        float4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = threadIdx.x + 256 * k, lr = i >> 4, lc = (i & 15) * 4;
+            v[k] = *reinterpret_cast<const float4 *>(in + (r0 + lr) * cols + c0 + lc);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = threadIdx.x + 256 * k, lr = i >> 4, lc = (i & 15) * 4;
+            if (root) { v[k].x = __fsqrt_rn(v[k].x); v[k].y = __fsqrt_rn(v[k].y); v[k].z = __fsqrt_rn(v[k].z); v[k].w = __fsqrt_rn(v[k].w); }
+            tile[lr][lc] = v[k].x; tile[lr][lc + 1] = v[k].y; tile[lr][lc + 2] = v[k].z; tile[lr][lc + 3] = v[k].w;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = threadIdx.x + 256 * k, lc = i >> 4, lr = (i & 15) * 4;
+            *reinterpret_cast<float4 *>(out + (c0 + lc) * rows + r0 + lr) =
+                make_float4(tile[lr][lc], tile[lr + 1][lc], tile[lr + 2][lc], tile[lr + 3][lc]);
+        }
+        return;
+    }
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;          // 64 x 4
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const long r = r0 + ty + 4 * k, c = c0 + tx;
+        if (r < rows && c < cols) {
+            const float x = in[r * cols + c];
+            tile[ty + 4 * k][tx] = root ? __fsqrt_rn(x) : x;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const long c = c0 + ty + 4 * k, r = r0 + tx;
+        if (r < rows && c < cols) out[c * rows + r] = tile[tx][ty + 4 * k];
+    }
+}
+
+// ---------------------------------------------------------------------------- fused lookups of one solve
+// idx planes [L][C][B] -> up to four channel-last outputs [L][B][C].  Tile = 64 channels x 32 rows: the index reads are
+// 64-byte runs along a plane, every output row segment is 256 bytes (128 for the u16 indices).
+constexpr int kGlRows = 32, kGlCh = 64;
+template <int N>
+__global__ void __launch_bounds__(256)
+k_gather_latents(const uint16_t *__restrict__ idx, long B, int C, const float *__restrict__ tab_sorted,
+                 const float *__restrict__ level_len, const float *__restrict__ models, float *__restrict__ out_z,
+                 float *__restrict__ out_raw, int raw_as_int, float *__restrict__ out_nb, uint16_t *__restrict__ out_idx) {
+    constexpr int T = table_size(N), N1 = N + 1;
+    __shared__ float tz[kGlCh][kGlRows + 1], tr[kGlCh][kGlRows + 1], tn[kGlCh][kGlRows + 1];
+    __shared__ uint16_t tq[kGlCh][kGlRows + 2];
+    const int l = blockIdx.y;
+    const long ctiles = (C + kGlCh - 1) / kGlCh;
+    const long r0 = ((long)blockIdx.x / ctiles) * kGlRows;
+    const int c0 = (int)((long)blockIdx.x % ctiles) * kGlCh;
+    const long E = B * (long)C;
+    {
+        const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 32 rows x 8 channels per step
+        const long r = r0 + tx;
+#pragma unroll
+        for (int k = 0; k < kGlCh / 8; ++k) {
+            const int lc = ty + 8 * k, c = c0 + lc;
+            if (r < B && c < C) {
+                const int q = min((int)idx[((long)l * C + c) * B + r], T - 1);      // foreign indices >= T stay inside the tables
+                const int lvl = N - __builtin_ctz((unsigned)q + 1u);
+                if (out_z) tz[lc][tx] = tab_sorted[(long)c * T + q];
+                if (out_raw) tr[lc][tx] = level_len ? level_len[((long)l * C + c) * N1 + lvl]
+                                                    : (raw_as_int ? __int_as_float(lvl) : (float)lvl);
+                if (out_nb) tn[lc][tx] = models[((long)l * C + c) * T + q];
+                if (out_idx) tq[lc][tx] = (uint16_t)q;
+            }
+        }
+    }
+    __syncthreads();
+    {
+        const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;     // 64 channels x 4 rows per step
+        const int c = c0 + tx;
+#pragma unroll
+        for (int k = 0; k < kGlRows / 4; ++k) {
+            const int lr = ty + 4 * k;
+            const long r = r0 + lr;
+            if (r < B && c < C) {
+                const long o = (long)l * E + r * C + c;
+                if (out_z) out_z[o] = tz[tx][lr];
+                if (out_raw) out_raw[o] = tr[tx][lr];
+                if (out_nb) out_nb[o] = tn[tx][lr];
+                if (out_idx) out_idx[o] = tq[tx][lr];
+            }
+        }
+    }
+}
+
+size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+int gather_latents(const uint16_t *idx, int64_t B, int32_t C, int32_t L, int32_t N, const float *tab_sorted, const float *level_len,
+                   const float *models, float *out_z, void *out_raw, float *out_nb, uint16_t *out_idx, hipStream_t st) {
+    const int64_t tiles = ((B + kGlRows - 1) / kGlRows) * ((C + kGlCh - 1) / kGlCh);
+    VBQ_REQUIRE(tiles <= 0x7fffffffll && L <= 65535, VBQ_ERR_UNSUPPORTED, "vbq_gather_latents_u16: grid too large");
+    const dim3 grid((unsigned)tiles, (unsigned)L);
+    const int raw_as_int = level_len == nullptr;
+#define VBQ_DISPATCH_N(NN)                                                                                                  \
+    case NN:                                                                                                                \
+        hipLaunchKernelGGL((k_gather_latents<NN>), grid, dim3(256), 0, st, idx, (long)B, (int)C, tab_sorted, level_len, models, \
+                           out_z, static_cast<float *>(out_raw), raw_as_int, out_nb, out_idx);                              \
+        break;
+    switch (N) {
+        VBQ_FOR_EACH_N(VBQ_DISPATCH_N)
+        default:
+            set_error("vbq_gather_latents_u16: max_bits_per_coord N=%d not built", N);
+            return VBQ_ERR_UNSUPPORTED;
+    }
+#undef VBQ_DISPATCH_N
+    VBQ_CHECK_LAUNCH("gather_latents");
+    return VBQ_OK;
+}
+
+}  // namespace
+}  // namespace vbq
+
+extern "C" int vbq_gather_latents_u16(const uint16_t *d_idx_planes, int64_t n_rows, int32_t n_ch, int32_t n_lambda, int32_t N,
+                                      const float *d_table_sorted, const float *d_level_len, const float *d_models,
+                                      float *d_out_zhat, void *d_out_raw_bits, float *d_out_num_bits, uint16_t *d_out_idx,
+                                      void *stream) {
+    using namespace vbq;
+    VBQ_REQUIRE(n_rows >= 0 && n_ch >= 1 && n_lambda >= 1 && N >= 0 && N <= 15, VBQ_ERR_INVALID_ARGUMENT,
+                "vbq_gather_latents_u16: bad sizes");
+    if (n_rows == 0) return VBQ_OK;
+    VBQ_REQUIRE(d_idx_planes && (d_out_zhat || d_out_raw_bits || d_out_num_bits || d_out_idx), VBQ_ERR_INVALID_ARGUMENT,
+                "vbq_gather_latents_u16: null pointer argument");
+    VBQ_REQUIRE((!d_out_zhat || d_table_sorted) && (!d_out_num_bits || d_models), VBQ_ERR_INVALID_ARGUMENT,
+                "vbq_gather_latents_u16: an output without its table");
+    return gather_latents(d_idx_planes, n_rows, n_ch, n_lambda, N, d_table_sorted, d_level_len, d_models, d_out_zhat, d_out_raw_bits,
+                          d_out_num_bits, d_out_idx, reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int vbq_prep_planes_f32(const float *d_means_bc, const float *d_spread_bc, int32_t spread_is_variance, int64_t n_rows,
+                                   int32_t n_ch, float *d_mu_cb, float *d_sigma_cb, void *stream) {
+    using namespace vbq;
+    VBQ_REQUIRE(n_rows >= 0 && n_ch >= 1, VBQ_ERR_INVALID_ARGUMENT, "vbq_prep_planes_f32: bad sizes");
+    if (n_rows == 0) return VBQ_OK;
+    VBQ_REQUIRE(d_means_bc && d_spread_bc && d_mu_cb && d_sigma_cb && d_means_bc != d_mu_cb && d_spread_bc != d_sigma_cb,
+                VBQ_ERR_INVALID_ARGUMENT, "vbq_prep_planes_f32: null or aliased pointers");
+    const int64_t tiles = ((n_rows + 63) / 64) * (((int64_t)n_ch + 63) / 64);
+    VBQ_REQUIRE(tiles <= 0x7fffffffll, VBQ_ERR_UNSUPPORTED, "vbq_prep_planes_f32: more than 2^31 - 1 tiles of 64 x 64");
+    const uintptr_t all = reinterpret_cast<uintptr_t>(d_means_bc) | reinterpret_cast<uintptr_t>(d_spread_bc) |
+                          reinterpret_cast<uintptr_t>(d_mu_cb) | reinterpret_cast<uintptr_t>(d_sigma_cb);
+    const int v4 = n_rows % 4 == 0 && n_ch % 4 == 0 && (all & 15) == 0;
+    hipLaunchKernelGGL(k_prep_planes, dim3((unsigned)tiles, 2), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), d_means_bc,
+                       d_spread_bc, (long)n_rows, (long)n_ch, d_mu_cb, d_sigma_cb, (int)(spread_is_variance != 0), v4);
+    VBQ_CHECK_LAUNCH("prep_planes");
+    return VBQ_OK;
+}
+
+extern "C" size_t vbq_compress_latents_workspace_bytes(int64_t n_rows, int32_t n_ch, int32_t n_lambda, int32_t N) {
+    if (n_rows < 0 || n_ch <= 0 || n_lambda <= 0 || N < 0) return 0;
+    const size_t E = (size_t)n_rows * (size_t)n_ch;
+    return 2 * vbq::align256(E * sizeof(float)) + vbq::align256((size_t)n_lambda * E * sizeof(uint16_t)) +
+           vbq::align256(vbq_quantize_workspace_bytes(n_ch, n_lambda, N));
+}
+
+extern "C" int vbq_compress_latents_f32(const float *d_means_bc, const float *d_spread_bc, int32_t spread_is_variance,
+                                        int64_t n_rows, int32_t n_ch, const float *d_table_lm, const float *d_table_sorted,
+                                        const float *d_level_len, const float *d_models, const double *h_lambdas,
+                                        int32_t n_lambda, int32_t N, float *d_out_zhat, void *d_out_raw_bits,
+                                        float *d_out_num_bits, void *d_workspace, size_t workspace_bytes, void *stream) {
+    using namespace vbq;
+    VBQ_REQUIRE(n_rows >= 0 && n_ch >= 1 && n_lambda >= 1, VBQ_ERR_INVALID_ARGUMENT, "vbq_compress_latents_f32: bad sizes");
+    if (n_rows == 0) return VBQ_OK;
+    const size_t need = vbq_compress_latents_workspace_bytes(n_rows, n_ch, n_lambda, N);
+    VBQ_REQUIRE(d_workspace && workspace_bytes >= need, VBQ_ERR_WORKSPACE, "vbq_compress_latents_f32: workspace of %zu bytes given, %zu needed",
+                workspace_bytes, need);
+    VBQ_REQUIRE((reinterpret_cast<uintptr_t>(d_workspace) & 255) == 0, VBQ_ERR_INVALID_ARGUMENT,
+                "vbq_compress_latents_f32: workspace must be 256-byte aligned");
+    const size_t E = (size_t)n_rows * (size_t)n_ch;
+    char *w = static_cast<char *>(d_workspace);
+    float *mu_cb = reinterpret_cast<float *>(w);
+    w += align256(E * sizeof(float));
+    float *sg_cb = reinterpret_cast<float *>(w);
+    w += align256(E * sizeof(float));
+    uint16_t *idx = reinterpret_cast<uint16_t *>(w);
+    w += align256((size_t)n_lambda * E * sizeof(uint16_t));
+    const size_t qws = vbq_quantize_workspace_bytes(n_ch, n_lambda, N);
+    int rc = vbq_prep_planes_f32(d_means_bc, d_spread_bc, spread_is_variance, n_rows, n_ch, mu_cb, sg_cb, stream);
+    if (rc != VBQ_OK) return rc;
+    rc = vbq_quantize_f32(mu_cb, sg_cb, n_rows, n_ch, VBQ_LAYOUT_CB, d_table_lm, d_level_len, h_lambdas, n_lambda, N, VBQ_MODE_F32,
+                          idx, nullptr, nullptr, w, qws, stream);
+    if (rc != VBQ_OK) return rc;
+    return vbq_gather_latents_u16(idx, n_rows, n_ch, n_lambda, N, d_table_sorted, d_level_len, d_models, d_out_zhat, d_out_raw_bits,
+                                  d_out_num_bits, nullptr, stream);
+}

@@ -948,7 +948,11 @@ int launch_notebook(const float *means, const float *stds, int64_t n, const doub
         bool fast_ok = !plain;                      // the tie certificate wants betas in a sane range
         for (int i = 0; i < Lc; ++i) fast_ok = fast_ok && (bc.beta[i] >= 1e-12 && bc.beta[i] <= 1e18);
         static const bool no_pruned = [] { const char *e = getenv("VBQ_NO_PRUNED"); return e && e[0] == '1'; }();
-        if (!plain && !no_pruned && Lc <= 2) {         // one or two betas per call (the notebook's own pattern): pruned descent
+        // The pruned descent stops once best <= w (n + 1): a bound on every deeper level's penalty that holds for w >= 0 only
+        // (with a negative beta deeper levels carry SMALLER penalties and can still win): such calls take the literal kernel.
+        bool nonneg = true;
+        for (int i = 0; i < Lc; ++i) nonneg = nonneg && bc.beta[i] >= 0.0;
+        if (!plain && !no_pruned && nonneg && Lc <= 2) {  // one or two betas per call (the notebook's own pattern): pruned descent
             int64_t gp = gx;
             const int64_t capp = (int64_t)num_cus() * 6 * 2;
             if (gp > capp) gp = capp;

@@ -1549,6 +1549,9 @@ int launch_quant_hull_idx10(const float *mu, const float *sg, int64_t n_per_ch, 
     static const bool off = [] { const char *e = getenv("VBQ_NO_HULL"); return e && e[0] == '1'; }();
     if (off || L < 16) return 1;                             // below that the thresholds cost more than the solves they replace
                                                              // (Kodak-24: 0.25 against 0.27 ms at 16 lambdas, 0.29 against 0.43 at 32)
+    // The emission addresses an index plane with a 32-bit BYTE offset from a scalar plane base (global_store_dword voff, v,
+    // s[plane]): planes of 2^31 elements or more (a 16-lambda sweep of that size is 64 GB of indices: it fits) go to K1.
+    if (2 * (uint64_t)E > 0xffffffffull) return 1;
     HullSweep sw;
     if (!build_hull_sweep(lam, L, sw)) return 1;
     const int64_t npairs = (n_per_ch + 1) / 2;

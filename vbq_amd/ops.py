@@ -337,6 +337,104 @@ def gather(idx: torch.Tensor, tab: torch.Tensor, n_ch: int, *, N: int = 10, layo
     return out
 
 
+def prep_planes(means_bc: torch.Tensor, spread_bc: torch.Tensor, *, spread_is_variance: bool = False,
+                out_mu: Optional[torch.Tensor] = None, out_sigma: Optional[torch.Tensor] = None):
+    """vbq_prep_planes_f32: channel-last [rows, C] means and spreads -> channel-major planes [C, rows] in ONE launch;
+    spread_is_variance: the spreads are exp(logvar), sigma = sqrt(.) is taken on the way (quantizer.py:197,202)."""
+    means_bc = _dev(means_bc, torch.float32, "means")
+    spread_bc = _dev(spread_bc, torch.float32, "spread")
+    if means_bc.dim() != 2 or means_bc.shape != spread_bc.shape:
+        raise ValueError(f"expected two [rows, C] tensors, got {tuple(means_bc.shape)} / {tuple(spread_bc.shape)}")
+    r, c = means_bc.shape
+    outs = []
+    for o, name in ((out_mu, "out_mu"), (out_sigma, "out_sigma")):
+        if o is None:
+            o = torch.empty((c, r), dtype=torch.float32, device=means_bc.device)
+        elif tuple(o.shape) != (c, r) or o.dtype != torch.float32 or not o.is_contiguous() or not o.is_cuda:
+            raise ValueError(f"{name} must be a contiguous f32 device tensor of shape {(c, r)}")
+        outs.append(o)
+    check(_lib.lib().vbq_prep_planes_f32(_ptr(means_bc), _ptr(spread_bc), int(bool(spread_is_variance)), r, c, _ptr(outs[0]),
+                                         _ptr(outs[1]), _stream(means_bc)), "vbq_prep_planes_f32")
+    return outs[0], outs[1]
+
+
+def gather_latents(idx_planes: torch.Tensor, *, N: int = 10, table_sorted: Optional[torch.Tensor] = None,
+                   level_len: Optional[torch.Tensor] = None, models: Optional[torch.Tensor] = None, want_zhat: bool = True,
+                   want_raw_bits: bool = True, want_num_bits: bool = False, want_idx: bool = False):
+    """vbq_gather_latents_u16: ONE pass over rank indices in planes [L, C, B] -> channel-last [L, B, C] results
+    (Z_hat f32, raw_num_bits int32 / f32 with level_len, num_bits f32, idx u16; None for the ones not asked for)."""
+    idx_planes = _dev(idx_planes, torch.uint16, "idx_planes")
+    if idx_planes.dim() != 3:
+        raise ValueError(f"idx_planes must be [L, C, B], got {tuple(idx_planes.shape)}")
+    L, Cc, B = idx_planes.shape
+    T = table_size(N)
+    if want_zhat:
+        table_sorted = _dev(table_sorted, torch.float32, "table_sorted")
+        if table_sorted.numel() != Cc * T:
+            raise ValueError(f"table_sorted has {table_sorted.numel()} entries, expected {Cc}*{T}")
+    if level_len is not None:
+        level_len = _dev(level_len, torch.float32, "level_len")
+        if tuple(level_len.shape) != (L, Cc, N + 1):
+            raise ValueError(f"level_len shape {tuple(level_len.shape)} != {(L, Cc, N + 1)}")
+    if want_num_bits:
+        models = _dev(models, torch.float32, "models")
+        if tuple(models.shape) != (L, Cc, T):
+            raise ValueError(f"models shape {tuple(models.shape)} != {(L, Cc, T)}")
+    dev = idx_planes.device
+    z = torch.empty((L, B, Cc), dtype=torch.float32, device=dev) if want_zhat else None
+    raw = torch.empty((L, B, Cc), dtype=torch.int32 if level_len is None else torch.float32, device=dev) if want_raw_bits else None
+    nb = torch.empty((L, B, Cc), dtype=torch.float32, device=dev) if want_num_bits else None
+    qi = torch.empty((L, B, Cc), dtype=torch.uint16, device=dev) if want_idx else None
+    check(_lib.lib().vbq_gather_latents_u16(_ptr(idx_planes), B, Cc, L, N, _ptr(table_sorted) if want_zhat else None, _ptr(level_len),
+                                            _ptr(models) if want_num_bits else None, _ptr(z), _ptr(raw), _ptr(nb), _ptr(qi),
+                                            _stream(idx_planes)), "vbq_gather_latents_u16")
+    return z, raw, nb, qi
+
+
+def compress_latents(means_bc: torch.Tensor, spread_bc: torch.Tensor, table_lm: torch.Tensor, table_sorted: torch.Tensor,
+                     lambdas: Sequence[float], *, N: int = 10, spread_is_variance: bool = False,
+                     level_len: Optional[torch.Tensor] = None, models: Optional[torch.Tensor] = None,
+                     workspace: Optional[torch.Tensor] = None):
+    """vbq_compress_latents_f32: the per-image call of quantizer.py:190-240 in one C call (planes, solve, fused lookups).
+    means / spreads channel-last [B, C]; returns (Z_hat f32, raw_num_bits int32 | f32, num_bits f32 | None), [L, B, C]."""
+    means_bc = _dev(means_bc, torch.float32, "means")
+    spread_bc = _dev(spread_bc, torch.float32, "spread")
+    if means_bc.dim() != 2 or means_bc.shape != spread_bc.shape:
+        raise ValueError(f"expected two [rows, C] tensors, got {tuple(means_bc.shape)} / {tuple(spread_bc.shape)}")
+    B, Cc = means_bc.shape
+    L = len(lambdas)
+    T = table_size(N)
+    if L < 1:
+        raise ValueError("need at least one lambda")
+    table_lm = _dev(table_lm, torch.float32, "table_lm")
+    table_sorted = _dev(table_sorted, torch.float32, "table_sorted")
+    if table_lm.numel() != Cc * T or table_sorted.numel() != Cc * T:
+        raise ValueError(f"tables must hold C*T = {Cc}*{T} entries")
+    if level_len is not None:
+        level_len = _dev(level_len, torch.float32, "level_len")
+        if tuple(level_len.shape) != (L, Cc, N + 1):
+            raise ValueError(f"level_len shape {tuple(level_len.shape)} != {(L, Cc, N + 1)}")
+    if models is not None:
+        models = _dev(models, torch.float32, "models")
+        if tuple(models.shape) != (L, Cc, T):
+            raise ValueError(f"models shape {tuple(models.shape)} != {(L, Cc, T)}")
+    dev = means_bc.device
+    h = _lib.lib()
+    wsb = h.vbq_compress_latents_workspace_bytes(B, Cc, L, N)
+    ws = workspace if workspace is not None else torch.empty(max(wsb, 256), dtype=torch.uint8, device=dev)
+    if ws.numel() * ws.element_size() < wsb or not ws.is_cuda:
+        raise ValueError(f"workspace must be a device tensor of at least {wsb} bytes")
+    z = torch.empty((L, B, Cc), dtype=torch.float32, device=dev)
+    raw = torch.empty((L, B, Cc), dtype=torch.int32 if level_len is None else torch.float32, device=dev)
+    nb = torch.empty((L, B, Cc), dtype=torch.float32, device=dev) if models is not None else None
+    if B:
+        check(h.vbq_compress_latents_f32(_ptr(means_bc), _ptr(spread_bc), int(bool(spread_is_variance)), B, Cc, _ptr(table_lm),
+                                         _ptr(table_sorted), _ptr(level_len), _ptr(models), _doubles(lambdas), L, N, _ptr(z),
+                                         _ptr(raw), _ptr(nb), _ptr(ws), ws.numel() * ws.element_size(), _stream(means_bc)),
+              "vbq_compress_latents_f32")
+    return z, raw, nb
+
+
 def transpose(x: torch.Tensor, out: Optional[torch.Tensor] = None):
     """vbq_transpose_f32: [rows, cols] f32 -> [cols, rows] (channel-last <-> channel-major planes)."""
     x = _dev(x, torch.float32, "x")

@@ -59,7 +59,13 @@ class HostStage:
     copies), `fn(*host_inputs) -> host_outputs` on the runtime's callback thread (hipLaunchHostFunc, ordered on the stream
     like a kernel, capturable into a HIP graph as a host node), pinned memory -> device tensors.  Used for the handful of
     -log2 values per (lambda, channel) that must come from NumPy's own float32 operations (quantizer.py:105-110,141-146)
-    when they cannot be tabulated."""
+    when they cannot be tabulated.
+
+    The callback runs Python on the HIP runtime's thread and needs the GIL: a thread that HOLDS the GIL while it blocks on the
+    device with a host node pending (a binding that does not release it around hipFree / hipDeviceSynchronize) would
+    deadlock.  torch's own synchronising calls release it.  An exception inside `fn` cannot propagate into the runtime: it is
+    kept in `error` and raised by `check()` -- callers of `enqueue()` must call `check()` after a synchronisation before they
+    trust the outputs (EntropyModelBuild.check does; the quantizer runs it before any table is read)."""
     _CB = _C.CFUNCTYPE(None, _C.c_void_p)
 
     def __init__(self, inputs, outputs, fn):
@@ -115,7 +121,11 @@ class EntropyModelBuild:
 
     def __init__(self, rows: int, n_ch: int, lambdas: Sequence[float], table_lm: torch.Tensor, *, N: int = 10,
                  add_n_smoothing=1, global_rows: Optional[int] = None, distributed: bool = False, group=None,
-                 level_group=None, n_chunks: Optional[int] = None, counts_dtype=None, keep_models: bool = True):
+                 level_group=None, n_chunks: Optional[int] = None, counts_dtype=None, keep_models: bool = True,
+                 buffers: Optional[dict] = None):
+        """buffers: a dict the caller keeps between builds -- the index planes, the solve's workspace and the -log2 tables
+        (device copies) of one shape are taken from it instead of being allocated / computed / uploaded again; every
+        OUTPUT tensor (histograms, length table, models) is new per object."""
         self.rows, self.C, self.N = int(rows), int(n_ch), int(N)
         self.lambdas = [float(l) for l in lambdas]
         self.L = len(self.lambdas)
@@ -136,17 +146,32 @@ class EntropyModelBuild:
         L, C, N1, T = self.L, self.C, N + 1, self.T
         if counts_dtype is None:       # int32 halves the all-reduce payload; exact while no bin can reach 2^31
             counts_dtype = torch.int32 if self.global_rows < 2 ** 31 else torch.int64
-        self.idx = torch.empty((L, C, self.rows), dtype=torch.uint16, device=self.dev)
+        buf = buffers if buffers is not None else {}
+
+        def kept(key, make):
+            t = buf.get(key)
+            if t is None:
+                if len(buf) > 16:             # a caller that walks through many shapes does not pile them up
+                    buf.clear()
+                t = buf[key] = make()
+            return t
+        self.idx = kept(("idx", L, C, self.rows, str(self.dev)),
+                        lambda: torch.empty((L, C, self.rows), dtype=torch.uint16, device=self.dev))
         self.level_counts = torch.zeros((L, C, N1), dtype=torch.int64, device=self.dev)
         # two rank-histogram buffers when sharded: step i's all-reduce runs while step i+1 fills the other one
         self._counts2 = [torch.zeros((L, C, T), dtype=counts_dtype, device=self.dev) for _ in range(2 if self.world > 1 else 1)]
         self._slot = 0
         self.counts = self._counts2[0]
-        self.ws = torch.empty(ops._lib.lib().vbq_quantize_workspace_bytes(C, L, N), dtype=torch.uint8, device=self.dev)
-        lut1 = _entropy.neg_log2_lut(self.global_rows, N1, add_n_smoothing, max_entries=max(1 << 20, 4 * L * C * N1))
-        lut2 = _entropy.neg_log2_lut(self.global_rows, T, add_n_smoothing, max_entries=max(1 << 20, L * C * T)) if keep_models else None
-        self.lut1 = torch.from_numpy(lut1).to(self.dev) if lut1 is not None else None
-        self.lut2 = torch.from_numpy(lut2).to(self.dev) if lut2 is not None else None
+        self.ws = kept(("ws", L, C, N, str(self.dev)),
+                       lambda: torch.empty(ops._lib.lib().vbq_quantize_workspace_bytes(C, L, N), dtype=torch.uint8, device=self.dev))
+
+        def lut(K, max_entries):              # (tensor | None,): None is a result worth keeping too
+            def make():
+                h = _entropy.neg_log2_lut(self.global_rows, K, add_n_smoothing, max_entries=max_entries)
+                return (torch.from_numpy(h).to(self.dev) if h is not None else None,)
+            return kept(("lut", self.global_rows, K, repr(add_n_smoothing), max_entries, str(self.dev)), make)[0]
+        self.lut1 = lut(N1, max(1 << 20, 4 * L * C * N1))
+        self.lut2 = lut(T, max(1 << 20, L * C * T)) if keep_models else None
         self.level_len = torch.empty((L, C, N1), dtype=torch.float32, device=self.dev)
         self.raw_models = torch.empty((L, C, N1), dtype=torch.float32, device=self.dev)
         # the model table is worth keeping on the device when it is small or can be tabulated; otherwise (C > 1 without a
@@ -299,6 +324,11 @@ class EntropyModelBuild:
         self._models_from(self._slot)
         self._models_current = True
         return self.models
+
+    @property
+    def has_host_stages(self) -> bool:
+        """Some -log2 step of this build runs NumPy on the HIP runtime's callback thread (HostStage)."""
+        return self._len_stage is not None or bool(self._model_stages)
 
     @property
     def graph_safe(self) -> bool:

@@ -17,6 +17,7 @@ There is no CPU path: without the HIP extension and a ROCm device the methods ra
 """
 from __future__ import annotations
 
+from collections.abc import MutableMapping
 from typing import Dict, Optional
 
 import numpy as np
@@ -46,6 +47,101 @@ def _default_device():
     return torch.device("cuda", torch.cuda.current_device())
 
 
+class DeviceModels(MutableMapping):
+    """dict[lamb] -> NumPy array [C, K] whose rows live ON THE DEVICE until somebody reads them on the host.
+
+    build_entropy_models leaves its three tables -- entropy_models, raw_code_length_entropy_models and the integer
+    histograms behind them -- where the kernels wrote them: compress_latents reads them there, and the 67 MB of models plus
+    the counts (Kodak-24, C = 256, 32 lambdas) cross PCIe only if a caller actually looks at them (`models[lamb]`, iteration
+    over values / items, pickling, `save`).  The first host read copies the whole stack once and runs the build's deferred
+    checks (EntropyModelBuild.check: histogram totals, host stages); the arrays are read-only, as the eager ones were (an
+    in-place edit would leave the device copy stale).  Assigning `models[lamb] = array` works as on a dict; the device
+    stack is then no longer used for the lookups (`device_rows` returns None and the caller rebuilds its copy)."""
+
+    def __init__(self, keys, stack: torch.Tensor, companions=None, on_read=None):
+        self._keys = list(keys)
+        self._index = {k: i for i, k in enumerate(self._keys)}
+        self._stack = stack
+        self._companions = dict(companions or {})
+        self._on_read = on_read
+        self._host = None
+        self._over = {}                      # entries the caller replaced or added
+        self._gone = set()
+
+    @property
+    def on_device(self) -> bool:
+        """True while no host copy has been made."""
+        return self._host is None
+
+    def _materialise(self):
+        if self._host is None:
+            if self._on_read is not None:
+                self._on_read()
+            h = self._stack.cpu().numpy()
+            h.setflags(write=False)
+            self._host = h
+        return self._host
+
+    def __getitem__(self, k):
+        if k in self._over:
+            return self._over[k]
+        if k in self._gone:
+            raise KeyError(k)
+        i = self._index[k]                   # KeyError as a dict
+        return self._materialise()[i]
+
+    def __setitem__(self, k, v):
+        self._over[k] = v
+        self._gone.discard(k)
+
+    def __delitem__(self, k):
+        if k in self._over:
+            del self._over[k]
+            if k in self._index:
+                self._gone.add(k)
+        elif k in self._index and k not in self._gone:
+            self._gone.add(k)
+        else:
+            raise KeyError(k)
+
+    def __iter__(self):
+        for k in self._keys:
+            if k not in self._gone:
+                yield k
+        for k in self._over:
+            if k not in self._index:
+                yield k
+
+    def __len__(self):
+        return len(self._keys) - len(self._gone) + sum(1 for k in self._over if k not in self._index)
+
+    def __contains__(self, k):
+        return k in self._over or (k in self._index and k not in self._gone)
+
+    def device_rows(self, keys, companion=None):
+        """The rows of `keys` as a device tensor [len(keys), C, K] (of the companion stack when named), or None when an
+        entry was replaced by the caller (the device stack no longer tells the whole story).  KeyError for unknown keys."""
+        keys = list(keys)
+        for k in keys:
+            if k not in self:
+                raise KeyError(k)
+        if any(k in self._over for k in keys):
+            return None
+        t = self._stack if companion is None else self._companions[companion]
+        if keys == self._keys:
+            return t
+        return t[[self._index[k] for k in keys]].contiguous()
+
+    def to_dict(self):
+        return {k: self[k] for k in self}
+
+    def __reduce__(self):                    # pickles as the plain dict of NumPy arrays it stands for
+        return (dict, (self.to_dict(),))
+
+    def __repr__(self):
+        return f"DeviceModels({len(self)} lambdas, {'device-resident' if self.on_device else 'host copy made'})"
+
+
 class ChannelwisePriorCDFQuantizer:
     def __init__(self, num_channels, max_bits_per_coord, float_type="float32", int_type="int32", device=None,
                  validate_inputs=False):
@@ -72,6 +168,9 @@ class ChannelwisePriorCDFQuantizer:
         st["_dev_cache"] = {}
         st["_device"] = None
         st["process_group"] = None
+        for k, v in list(st.items()):          # device-resident tables travel as the dicts of NumPy arrays they stand for
+            if isinstance(v, DeviceModels):
+                st[k] = v.to_dict()
         return st
 
     def __setstate__(self, st):
@@ -190,16 +289,11 @@ class ChannelwisePriorCDFQuantizer:
 
     # ------------------------------------------------------------------ the solve
     def _prep(self, batch_means, batch_stds):
-        mu = torch.as_tensor(_to_numpy(batch_means) if not isinstance(batch_means, torch.Tensor) else batch_means)
-        sg = torch.as_tensor(_to_numpy(batch_stds) if not isinstance(batch_stds, torch.Tensor) else batch_stds)
-        mu = mu.to(self.device, torch.float32)
-        sg = sg.to(self.device, torch.float32)
-        if mu.dim() != 2 or mu.shape[1] != self.num_channels or mu.shape != sg.shape:
-            raise ValueError(f"expected means/stds of shape [B, {self.num_channels}], got {tuple(mu.shape)} / {tuple(sg.shape)}")
+        mu, sg = self._batch_dev(batch_means, batch_stds)
         if getattr(self, "validate_inputs", False):
             ops.check_inputs(mu.contiguous(), sg.contiguous())
-        # channel-major planes [C, B]
-        return ops.transpose(mu.contiguous()), ops.transpose(sg.contiguous())
+        # channel-major planes [C, B], both in one launch
+        return ops.prep_planes(mu, sg)
 
     def _keyed_dev(self, name: str, arrays, builder):
         """Device copy of a table assembled from per-lambda model arrays, rebuilt only when one of those arrays is
@@ -224,9 +318,14 @@ class ChannelwisePriorCDFQuantizer:
 
     def _level_len_dev(self, lambs) -> Optional[torch.Tensor]:
         """quantizer.py:166,171-175: None for raw lengths, else f32 [L, C, N+1] = n + overhead."""
-        if not self.raw_code_length_entropy_models:
+        rm = self.raw_code_length_entropy_models
+        if not rm:
             return None
-        arrays = [self.raw_code_length_entropy_models[lamb] for lamb in lambs]      # KeyError as in the reference
+        if isinstance(rm, DeviceModels):       # still where the build wrote it: no host round trip
+            t = rm.device_rows(lambs, "level_len")                                  # KeyError as in the reference
+            if t is not None:
+                return t
+        arrays = [rm[lamb] for lamb in lambs]                                       # KeyError as in the reference
         return self._keyed_dev("level_len", arrays, lambda: self._level_len_host(lambs))
 
     def _level_len_host(self, lambs) -> torch.Tensor:
@@ -246,23 +345,42 @@ class ChannelwisePriorCDFQuantizer:
     def _rank_levels_dev(self):
         return self._dev("rank_levels", lambda: torch.from_numpy(_entropy.rank_levels(self.max_bits_per_coord)))
 
+    def _workspace(self, name: str, nbytes: int) -> torch.Tensor:
+        """A persistent device workspace, grown on demand (planes + index planes of the per-image call)."""
+        ws = self._dev_cache.get(name)
+        if ws is None or ws.numel() < nbytes or ws.device != self.device:
+            ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=self.device)
+            self._dev_cache[name] = ws
+        return ws
+
+    def _latents_call(self, means_bc, spread_bc, lambs, *, spread_is_variance, level_len, models):
+        """vbq_compress_latents_f32: planes, solve and the fused lookups of one batch in ONE C call (three launches).
+        -> (Z_hat, raw_num_bits, num_bits | None), channel-last [L, B, C] device tensors."""
+        from . import _lib
+        N, C = self.max_bits_per_coord, self.num_channels
+        if getattr(self, "validate_inputs", False):
+            ops.check_inputs(means_bc.contiguous(), (torch.sqrt(spread_bc) if spread_is_variance else spread_bc).contiguous())
+        B = means_bc.shape[0]
+        ws = self._workspace("_ws_latents", _lib.lib().vbq_compress_latents_workspace_bytes(B, C, len(lambs), N))
+        return ops.compress_latents(means_bc, spread_bc, self._table_dev(), self._sorted_dev(), [float(l) for l in lambs], N=N,
+                                    spread_is_variance=spread_is_variance, level_len=level_len, models=models, workspace=ws)
+
+    def _batch_dev(self, batch_means, batch_stds):
+        mu = torch.as_tensor(_to_numpy(batch_means) if not isinstance(batch_means, torch.Tensor) else batch_means)
+        sg = torch.as_tensor(_to_numpy(batch_stds) if not isinstance(batch_stds, torch.Tensor) else batch_stds)
+        mu = mu.to(self.device, torch.float32)
+        sg = sg.to(self.device, torch.float32)
+        if mu.dim() != 2 or mu.shape[1] != self.num_channels or mu.shape != sg.shape:
+            raise ValueError(f"expected means/stds of shape [B, {self.num_channels}], got {tuple(mu.shape)} / {tuple(sg.shape)}")
+        return mu, sg
+
     def compress_batch_channel_latents(self, batch_means, batch_stds, lambs, return_np=True, **kwargs):
         """quantizer.py:156-188 -> (Z_hat_dict, num_bits_dict), each dict[lamb] -> [B, C].
         num_bits is int32 (raw bit lengths) before the raw-length entropy models exist and
         float32 (n + overhead) afterwards, as in the reference."""
         lambs = list(lambs)
-        N, C = self.max_bits_per_coord, self.num_channels
-        mu_cb, sg_cb = self._prep(batch_means, batch_stds)
-        level_len = self._level_len_dev(lambs)
-        idx = self._solve_idx(mu_cb, sg_cb, lambs, level_len)                        # [L, C, B]
-        zhat = ops.gather(idx, self._sorted_dev(), C, N=N, layout="cb", out_layout="bc")   # [L, B, C] f32
-        lev = self._rank_levels_dev()
-        if level_len is None:
-            tab = lev.to(torch.float32).expand(C, -1).contiguous()                   # [C, T]: level of every rank
-            bits = ops.gather(idx, tab, C, N=N, layout="cb", out_layout="bc").to(torch.int32)
-        else:
-            tab = torch.gather(level_len, 2, lev.expand(len(lambs), C, -1))          # [L, C, T]: length of every rank
-            bits = ops.gather(idx, tab.contiguous(), C, N=N, layout="cb", out_layout="bc")
+        mu, sg = self._batch_dev(batch_means, batch_stds)
+        zhat, bits, _ = self._latents_call(mu, sg, lambs, spread_is_variance=False, level_len=self._level_len_dev(lambs), models=None)
         Z_hat_dict, num_bits_dict = {}, {}
         for i, lamb in enumerate(lambs):
             z, b = zhat[i], bits[i]                                                  # B x C
@@ -290,7 +408,9 @@ class ChannelwisePriorCDFQuantizer:
 
     def build_entropy_models_from_latents(self, batch_means, batch_stds, lambs, add_n_smoothing):
         """The body of quantizer.py:94-150 on (B x C) means/stds: vbq_amd.pipeline.EntropyModelBuild (pass 1 = solve +
-        bit-length histogram in one kernel, length table on the device, pass 2 = solve with K2 one chunk behind).
+        bit-length histogram in one kernel, length table on the device, pass 2 = solve + rank histogram + models).
+        NOTHING here waits for the device: the three tables stay where the kernels wrote them behind dict-like views
+        (`DeviceModels`) and reach NumPy when a caller reads them -- compress_latents never does.
         A rebuild starts from raw lengths again.  (In the reference a second build on the same object would feed the
         float "n + overhead" lengths of the first one to np.bincount, :96,104,166, which raises TypeError; starting
         over is the documented divergence)"""
@@ -305,37 +425,51 @@ class ChannelwisePriorCDFQuantizer:
             t = torch.tensor([B], dtype=torch.int64, device=self.device)
             dist.all_reduce(t, group=self.process_group)
             B_global = int(t.item())
+        # the index planes, the solve's workspace and the -log2 tables are kept between builds of one shape; the OUTPUT
+        # tensors are new every time (the dicts of an earlier build keep theirs)
         build = EntropyModelBuild(B, C, [float(l) for l in lambs], self._table_dev(), N=N, add_n_smoothing=add_n_smoothing,
                                   global_rows=B_global, distributed=distributed, group=self.process_group,
-                                  counts_dtype=torch.int64, keep_models=self._strict)
+                                  counts_dtype=torch.int32 if B_global < 2 ** 31 else torch.int64, keep_models=self._strict,
+                                  buffers=self._dev_cache.setdefault("_build_buffers", {}))
         self.raw_code_length_entropy_models = None
         build.pass1(mu_cb, sg_cb, None)
         level_len, raw_models = build.lengths()
-        raw_models = raw_models.cpu().numpy()
-        self.raw_code_length_entropy_models = {lamb: raw_models[i] for i, lamb in enumerate(lambs)}
         # pass 2: corrected lengths -> per-channel histogram of the code points (:118-148)
         _, counts = build.pass2(mu_cb, sg_cb, level_len)
         models_dev = build.finish_models()
-        if models_dev is not None:
-            models = models_dev.cpu().numpy()
-            counts = counts.cpu().numpy()
-        else:
-            build.wait()
-            counts = counts.cpu().numpy()
-            if not self._strict:   # qidx is the FIRST sorted position of a repeated value (:135)
-                merged = np.zeros_like(counts)
-                for c in range(self.num_channels):
-                    np.add.at(merged[:, c, :], (slice(None), self._canon[c]), counts[:, c, :])
-                counts = merged
-            models = _entropy.neg_log2_freq(counts, add_n_smoothing)                # [L, C, T] f32
-        self.entropy_models = {lamb: models[i] for i, lamb in enumerate(lambs)}
-        # kept for the entropy coder (vbq_amd.coder): the integer histograms behind the models
-        self._code_counts = {lamb: counts[i] for i, lamb in enumerate(lambs)}
         self._add_n_smoothing = add_n_smoothing
         self._dev_cache.pop("entropy_models", None)
         self._dev_cache.pop("level_len", None)
-        if models_dev is not None:   # the device copies compress_latents will ask for are already here
-            self._dev_cache["entropy_models"] = ([self.entropy_models[lamb] for lamb in lambs], models_dev)
+        if models_dev is not None:
+            state = {"done": False}
+
+            def deferred_checks():           # first host read of any of the three tables (synchronises)
+                if not state["done"]:
+                    state["done"] = True
+                    build.check()
+
+            if build.has_host_stages:        # a failed NumPy stage must not go unnoticed by device-only callers either
+                deferred_checks()
+            self.raw_code_length_entropy_models = DeviceModels(lambs, raw_models, {"level_len": level_len}, deferred_checks)
+            self.entropy_models = DeviceModels(lambs, models_dev, None, deferred_checks)
+            # kept for the entropy coder (vbq_amd.coder): the integer histograms behind the models
+            self._code_counts = DeviceModels(lambs, counts, None, deferred_checks)
+            return None
+        # repeated f32 code points (or a model table too large to keep): the counts go to the host
+        build.wait()
+        torch.cuda.synchronize(self.device)
+        build.check()
+        raw_models = raw_models.cpu().numpy()
+        self.raw_code_length_entropy_models = {lamb: raw_models[i] for i, lamb in enumerate(lambs)}
+        counts = counts.cpu().numpy()
+        if not self._strict:   # qidx is the FIRST sorted position of a repeated value (:135)
+            merged = np.zeros_like(counts)
+            for c in range(self.num_channels):
+                np.add.at(merged[:, c, :], (slice(None), self._canon[c]), counts[:, c, :])
+            counts = merged
+        models = _entropy.neg_log2_freq(counts, add_n_smoothing)                    # [L, C, T] f32
+        self.entropy_models = {lamb: models[i] for i, lamb in enumerate(lambs)}
+        self._code_counts = {lamb: counts[i] for i, lamb in enumerate(lambs)}
         self._dev_cache["level_len"] = ([self.raw_code_length_entropy_models[lamb] for lamb in lambs], level_len)
         for d in (self.entropy_models, self.raw_code_length_entropy_models):
             for a in d.values():
@@ -347,34 +481,37 @@ class ChannelwisePriorCDFQuantizer:
         return list(sorted(self.entropy_models.keys()))
 
     # ------------------------------------------------------------------ compression (quantizer.py:190-256)
-    def compress_latents(self, posterior_means, posterior_logvars, lambs, return_np=True):
-        """quantizer.py:190-240.  return_np=False keeps the per-lambda results on the device (torch tensors shaped like the
-        latents): no 150 MB device-to-host copy per Kodak image x 32 lambdas, which is what bounds the NumPy form (PCIe).
-        The reference returns NumPy arrays (np.reshape moves to the CPU, :237); that is the default here too."""
-        lambs = list(lambs)
-        N, C = self.max_bits_per_coord, self.num_channels
-        shape = tuple(np.shape(posterior_means))
-        m = posterior_means if isinstance(posterior_means, torch.Tensor) else torch.from_numpy(_to_numpy(posterior_means))
-        lv = posterior_logvars if isinstance(posterior_logvars, torch.Tensor) else torch.from_numpy(_to_numpy(posterior_logvars))
-        batch_means, batch_stds = self._flatten(m.to(self.device, torch.float32), lv.to(self.device, torch.float32))
-        mu_cb, sg_cb = self._prep(batch_means, batch_stds)
-        level_len = self._level_len_dev(lambs)
-        idx = self._solve_idx(mu_cb, sg_cb, lambs, level_len)                        # [L, C, B]
-        zhat = ops.gather(idx, self._sorted_dev(), C, N=N, layout="cb", out_layout="bc")   # [L, B, C]
-        lev = self._rank_levels_dev()
-        if level_len is None:
-            tab = lev.to(torch.float32).expand(C, -1).contiguous()
-            raw_bits = ops.gather(idx, tab, C, N=N, layout="cb", out_layout="bc").to(torch.int32)
-        else:
-            tab = torch.gather(level_len, 2, lev.expand(len(lambs), C, -1)).contiguous()
-            raw_bits = ops.gather(idx, tab, C, N=N, layout="cb", out_layout="bc")
+    def _models_dev(self, lambs) -> torch.Tensor:
+        """entropy_models of `lambs` as f32 [L, C, T] on the device, indexed by RANK."""
+        em = self.entropy_models
+        if isinstance(em, DeviceModels):
+            t = em.device_rows(lambs)                                                # KeyError as in the reference
+            if t is not None:
+                return t
+
         def models_host():
-            models = np.stack([np.asarray(self.entropy_models[lamb]) for lamb in lambs]).astype(np.float32)   # [L, C, T]
+            models = np.stack([np.asarray(em[lamb]) for lamb in lambs]).astype(np.float32)               # [L, C, T]
             if not self._strict:   # the reference indexes with the canonical qidx; same value either way once
                 models = np.stack([np.take_along_axis(mm, self._canon, axis=1) for mm in models])        # mapped per rank
             return torch.from_numpy(models)
-        models_dev = self._keyed_dev("entropy_models", [self.entropy_models[lamb] for lamb in lambs], models_host)
-        num_bits = ops.gather(idx, models_dev, C, N=N, layout="cb", out_layout="bc")                     # :226-228
+        return self._keyed_dev("entropy_models", [em[lamb] for lamb in lambs], models_host)
+
+    def compress_latents(self, posterior_means, posterior_logvars, lambs, return_np=True):
+        """quantizer.py:190-240.  One torch op (exp) and ONE C call = three launches (vbq_compress_latents_f32: planes with
+        sigma = sqrt(exp(logvar)) folded in, the solve, and one pass over the indices that writes Z_hat, raw_num_bits and
+        num_bits channel-last).  return_np=False keeps the per-lambda results on the device (torch tensors shaped like the
+        latents): no 150 MB device-to-host copy per Kodak image x 32 lambdas, which is what bounds the NumPy form (PCIe).
+        The reference returns NumPy arrays (np.reshape moves to the CPU, :237); that is the default here too."""
+        lambs = list(lambs)
+        C = self.num_channels
+        shape = tuple(np.shape(posterior_means))
+        m = posterior_means if isinstance(posterior_means, torch.Tensor) else torch.from_numpy(_to_numpy(posterior_means))
+        lv = posterior_logvars if isinstance(posterior_logvars, torch.Tensor) else torch.from_numpy(_to_numpy(posterior_logvars))
+        m, lv = m.to(self.device, torch.float32), lv.to(self.device, torch.float32)
+        assert lv.shape[-1] == C                                                     # quantizer.py:195
+        var = torch.exp(lv)                            # quantizer.py:197; the ** 0.5 of :202 is taken in the planes kernel
+        zhat, raw_bits, num_bits = self._latents_call(m.reshape(-1, C), var.reshape(-1, C), lambs, spread_is_variance=True,
+                                                      level_len=self._level_len_dev(lambs), models=self._models_dev(lambs))
         out_keys = ("Z_hat", "raw_num_bits", "num_bits_cl", "num_bits")
         output = {key: dict() for key in out_keys}
         L = len(lambs)
@@ -397,10 +534,11 @@ class ChannelwisePriorCDFQuantizer:
                 host[key] = h[:t.numel()].view(t.shape)
             torch.cuda.current_stream(self.device).synchronize()
             arrs = {key: np.array(h.numpy().reshape((L,) + shape)) for key, h in host.items()}    # [L, B, C] -> L x latent shape (:237)
+        has_cl = bool(self.raw_code_length_entropy_models)
         for i, lamb in enumerate(lambs):
             output["Z_hat"][lamb] = arrs["Z_hat"][i]
             output["raw_num_bits"][lamb] = arrs["raw_num_bits"][i]
-            if self.raw_code_length_entropy_models:
+            if has_cl:
                 output["num_bits_cl"][lamb] = output["raw_num_bits"][lamb]          # :231-232
             output["num_bits"][lamb] = arrs["num_bits"][i]
         return output
