@@ -266,3 +266,24 @@ def test_level_counts_single_launch_above_5e8_rows(ops):
     raw_len = torch.arange(N + 1, dtype=torch.float32, device="cuda").expand(3, 1, -1).contiguous()
     lc_h = ops.level_counts(mu, sg, tabd, lam, N=N, level_len=raw_len)                  # K1h: same lengths through the dense counting kernel
     assert torch.equal(lc_h, via)
+
+
+@pytest.mark.timeout(1200)
+def test_raw_length_sweep_above_2e31_elements(ops):
+    """A 16-lambda raw-length sweep (K1e's kind of call) over 2^31 + 2^20 elements: K1e addresses an index plane with a 32-bit
+    byte offset, so planes of 2^31 elements or more must go to K1.  69 GB of indices + 17 GB of inputs: it fits.
+    Oracle windows at the start, around element 2^31 (where a wrapped offset would land at the front of the plane) and at the
+    end; the front window is checked AFTER the whole launch, so a wrapped store would have overwritten it."""
+    free, _ = torch.cuda.mem_get_info()
+    n = (1 << 31) + (1 << 20)
+    if free < 100 * (1 << 30):
+        pytest.skip("needs 100 GB of free device memory")
+    lam16 = [float(v) for v in 2.0 ** np.linspace(-8, 7, 16)]
+    mu, sg = device_inputs(n, seed=8)
+    tab = gaussian_table(1.2355)
+    idx = ops.quantize(mu, sg, torch.from_numpy(tab).cuda(), lam16, N=N)
+    torch.cuda.synchronize()
+    assert idx.shape == (16, n)
+    check_windows(idx, mu, sg, tab, lam16, None, windows(n, [(1 << 31) - W // 2, (1 << 30) - W // 2, (1 << 20) - W // 2]))
+    cnt = ops.histogram(idx, 1, N=N)
+    assert torch.all(cnt.sum(dim=-1) == n)

@@ -408,3 +408,20 @@ def test_caller_length_tables_outside_the_certificate_range(ops):
     lev = O.levels_of_sorted_ranks(N)[want]
     wl = np.stack([[np.bincount(lev[l, :, c], minlength=N + 1) for c in range(C)] for l in range(len(lam))])
     assert np.array_equal(host(lc), wl)
+
+
+def test_notebook_one_beta_negative_or_zero(ops):
+    """One or two betas per call normally take the pruned descent (K1np), whose stop rule best <= w (n + 1) needs w >= 0: with
+    a NEGATIVE beta deeper levels carry smaller penalties and can still win -- such calls must take the literal
+    kernel and agree with the brute force; beta = 0 stays on the pruned kernel."""
+    rng = np.random.default_rng(19)
+    means = rng.normal(-0.08, 1.23, 20011).astype(np.float32)
+    stds = np.exp(rng.normal(-2, 0.7, 20011)).astype(np.float32)
+    pts, lens = O.notebook_code_book(O.empirical_std(means), N)
+    rank_of_slot = O.level_major_to_rank(N)
+    for betas in ([-0.5], [-3.0, 2.0], [0.0], [0.0, -1e-3], [1e-3]):
+        idx, val = ops.quantize_notebook(dev(means), dev(stds), dev(pts), betas, N=N)
+        for i, b in enumerate(betas):
+            v, slot = CO.compress_coordinates(means, stds, b, pts, lens, threads=8)
+            assert np.array_equal(host(val)[i], v), betas
+            assert np.array_equal(host(idx)[i].astype(np.int64), rank_of_slot[slot]), betas
