@@ -39,7 +39,7 @@ k_prep_planes(const float *__restrict__ in0, const float *__restrict__ in1, long
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int i = threadIdx.x + 256 * k, lr = i >> 4, lc = (i & 15) * 4;
-            if (root) { v[k].x = __fsqrt_rn(v[k].x); v[k].y = __fsqrt_rn(v[k].y); v[k].z = __fsqrt_rn(v[k].z); v[k].w = __fsqrt_rn(v[k].w); }
+            if (root) { v[k].x = sqrtf(v[k].x); v[k].y = sqrtf(v[k].y); v[k].z = sqrtf(v[k].z); v[k].w = sqrtf(v[k].w); }
             tile[lr][lc] = v[k].x; tile[lr][lc + 1] = v[k].y; tile[lr][lc + 2] = v[k].z; tile[lr][lc + 3] = v[k].w;
         }
         __syncthreads();
@@ -57,7 +57,7 @@ k_prep_planes(const float *__restrict__ in0, const float *__restrict__ in1, long
         const long r = r0 + ty + 4 * k, c = c0 + tx;
         if (r < rows && c < cols) {
             const float x = in[r * cols + c];
-            tile[ty + 4 * k][tx] = root ? __fsqrt_rn(x) : x;
+            tile[ty + 4 * k][tx] = root ? sqrtf(x) : x;
         }
     }
     __syncthreads();

@@ -58,7 +58,7 @@ k_normalize_t(const float *__restrict__ emb, long V, int K, int Kp, long Vp, flo
         __syncthreads();
     }
     if (tid < 64) {
-        dn[tid] = __fadd_rn(1e-8f, __fsqrt_rn(s));
+        dn[tid] = __fadd_rn(1e-8f, sqrtf(s));
         if (v0 + tid < Vp) den[v0 + tid] = dn[tid];
     }
     __syncthreads();
