@@ -905,6 +905,30 @@ def run_call_patterns(torch, dev, steps=10, warmup=3):
                                 {"planes_kernel_ms": planes_ms, "input_transposes_ms": tr_in, "output_transpose_ms": tr_out,
                                  "facade_over_planes_plus_transposes": ms / (planes_ms + tr_in + tr_out)})
     torch.cuda.empty_cache()
+    # (2b) the same call with the results left as the kernels write them: no transpose back (out_layout="planes")
+    def facade_planes():
+        res["idx"] = vbq_amd.quantize(mu_bc, sg_bc, LAMBDAS, table=tab, out_layout="planes")
+    ms = event_ms(torch, facade_planes, steps, warmup)
+    ok = bool(np.array_equal(res["idx"][:, :, :n].cpu().numpy().transpose(0, 2, 1), oracle(LAMBDAS)))
+    prep_ms = event_ms(torch, lambda: ops.prep_planes(mu_bc, sg_bc), steps, 2)
+    res.clear()
+    out["facade_bc_L32_planes_out"] = line(ms, L, "vbq_prep_planes_f32 + k_quant_hull_idx",
+                                           "vbq_amd.quantize(mu[B, C], sigma[B, C], lmbda[32], table, out_layout='planes'): "
+                                           "channel-last in, index planes [L, C, B] out", ok,
+                                           {"planes_kernel_ms": planes_ms, "prep_planes_ms": prep_ms,
+                                            "facade_over_planes_plus_prep": ms / (planes_ms + prep_ms)})
+    # (2c) Z_hat alone, channel-last (return_values=True, return_indices=False): solve on planes + ONE pass that looks the values
+    #      up and changes the layout (vbq_gather_latents_u16)
+    def facade_values():
+        res["z"] = vbq_amd.quantize(mu_bc, sg_bc, LAMBDAS, table=tab, return_values=True, return_indices=False)
+    ms = event_ms(torch, facade_values, steps, warmup)
+    srt_h = np.sort(tab_h, axis=1)
+    ok = bool(np.array_equal(res["z"][:, :n].cpu().numpy(), srt_h[np.arange(C)[None, None, :], oracle(LAMBDAS).astype(np.int64)]))
+    res.clear()
+    out["facade_bc_L32_values_out"] = line(ms, L, "vbq_prep_planes_f32 + k_quant_hull_idx + k_gather_latents",
+                                           "vbq_amd.quantize(..., return_values=True, return_indices=False): channel-last in, "
+                                           "Z_hat channel-last out (f32: 4 B per latent written instead of 2)", ok)
+    torch.cuda.empty_cache()
     # (3) the sweep of post_process.py:115 through the same call (16 lambdas, raw lengths)
     L16 = len(LAMBDAS_16)
     idx = torch.empty((L16, C, rows), dtype=torch.uint16, device=dev)
@@ -923,7 +947,10 @@ def run_call_patterns(torch, dev, steps=10, warmup=3):
     med = float(np.median([o["ms"] for o in one]))
     out["kodak24_c256_L1"] = line(med, 1, "k_quant_pruned / k_quant_fast (one lambda)", "quantize(mu, sigma, lmbda) with ONE lambda per call, "
                                   "planes in, indices out; median over five lambdas of the sweep", oks, {"per_lambda": one})
-    del idx, mu, sg, mu_bc, sg_bc
+    del idx
+    torch.cuda.empty_cache()
+    out.update(run_api_methods(torch, dev, mu_h, sg_h, mu_bc, sg_bc, tab_h, steps=steps, warmup=warmup))
+    del mu, sg, mu_bc, sg_bc
     torch.cuda.empty_cache()
     # (5) the notebook's calls: compress_coordinates(means, stds, beta) with one beta (ipynb:466) and the 50-beta sweep of
     #     cell 32 (ipynb:1102) in one launch; 100000 x 100 embeddings
@@ -951,6 +978,145 @@ def run_call_patterns(torch, dev, steps=10, warmup=3):
                     "parity_vs_oracle_on_sample": bool(ok),
                     "workload": f"embeddings_1e7: {WORKLOADS['embeddings_1e7'][2]}; {what}; notebook arithmetic (f64 squared error, ipynb:429-443), indices out"}
         del ix
+    return out
+
+
+def run_api_methods(torch, dev, mu_h, sg_h, mu_bc, sg_bc, tab_h, steps=10, warmup=3):
+    """The reference-facing METHODS under the clock (not the pipeline object behind them):
+      build_entropy_models_api   ChannelwisePriorCDFQuantizer.build_entropy_models_from_latents end to end on the Kodak-24
+                                 tensor (what post_process.py:103 triggers after the encoder), channel-last device tensors in,
+                                 nothing read on the host: K calls back to back, one synchronisation at the end;
+      compress_latents_image     the per-image call of the evaluation loop (utils.py:542 -> quantizer.py:190-240): one image
+                                 [1, 32, 48, 256], the 16 lambdas of post_process.py:115, corrected lengths, results left on
+                                 the device (return_np=False) and as NumPy arrays (the reference's form; PCIe-bound).
+    Parity: the three tables against a second build through the pipeline object and NumPy's -log2; the image's Z_hat /
+    raw_num_bits / num_bits against the C oracle's indices pushed through the same tables."""
+    import vbq_amd
+    from vbq_amd import entropy, ops
+    from vbq_amd.pipeline import EntropyModelBuild
+    from oracle import c_oracle as CO, vbq_oracle as O
+    out = {}
+    rows, C = mu_h.shape
+    E = rows * C
+
+    class _Table:                                             # prior stand-in: inverse_cdf returns the bench's code book
+        def inverse_cdf(self, xi):
+            return np.ascontiguousarray(tab_h.T)
+    q = vbq_amd.ChannelwisePriorCDFQuantizer(C, N_BITS)
+    q.build_code_points(_Table())
+    for key, lams in (("build_entropy_models_api", LAMBDAS), ("build_entropy_models_api_L16", LAMBDAS_16)):
+        L = len(lams)
+
+        def build_call():
+            q.build_entropy_models_from_latents(mu_bc, sg_bc, lams, 1)
+        for _ in range(warmup):
+            build_call()
+        clock_ramp(torch, build_call, min(RAMP_S, 0.15))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            build_call()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        on_dev = bool(q.entropy_models.on_device and q.raw_code_length_entropy_models.on_device)
+        # the pipeline object on the same planes (what the headline times), for the ratio and as the second route
+        mu_p, sg_p = ops.prep_planes(mu_bc, sg_bc)
+        build = EntropyModelBuild(rows, C, lams, torch.from_numpy(tab_h).to(dev), N=N_BITS, add_n_smoothing=1)
+        pipe_ms = event_ms(torch, lambda: (ops.prep_planes(mu_bc, sg_bc, out_mu=mu_p, out_sigma=sg_p), build.run(mu_p, sg_p)), steps, 2)
+        torch.cuda.synchronize()
+        got_m = np.stack([q.entropy_models[l] for l in lams])                     # first host read (one copy + deferred checks)
+        got_r = np.stack([q.raw_code_length_entropy_models[l] for l in lams])
+        got_c = np.stack([q._code_counts[l] for l in lams])
+        ok = bool(np.array_equal(got_m, build.models.cpu().numpy()) and np.array_equal(got_r, build.raw_models.cpu().numpy())
+                  and np.array_equal(got_c, build.counts.cpu().numpy())
+                  and np.array_equal(got_m, entropy.neg_log2_freq(got_c, 1)) and int(got_c.sum()) == E * L)
+        alg = E * (8 + 2 * L)
+        out[key] = {"ms_per_step": ms, "value": E * L / (ms * 1e-3), "unit": "latents/s",
+                    "roofline": {"bound": "hbm", "limited_by": "valu issue", "kernel": "k_quant_fast (inside the method)",
+                                 "achieved": alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                                 # the whole call against ONE pass's algorithmic bytes: a lower bound of the kernel's fraction
+                                 "frac": alg / (ms * 1e-3) / HBM_PEAK, "algorithmic_bytes_per_launch": alg, "avg_launch_ms": ms},
+                    "pipeline_step_ms_same_inputs": pipe_ms, "api_over_pipeline_step": ms / pipe_ms,
+                    "tables_device_resident_after_the_calls": on_dev, "parity_vs_oracle_on_sample": ok,
+                    "workload": f"kodak24_c256 [{rows} x {C}]: ChannelwisePriorCDFQuantizer.build_entropy_models_from_latents(means, stds, "
+                                f"{L} lambdas, add_n_smoothing=1), channel-last device tensors in, no host read; {steps} calls, one synchronisation"}
+        del build, mu_p, sg_p
+        torch.cuda.empty_cache()
+    # ---- one image through compress_latents with the 16-lambda models built above
+    lams = LAMBDAS_16
+    L = len(lams)
+    H, W = 32, 48
+    B = H * W
+    m_img = mu_bc[:B].reshape(1, H, W, C).contiguous()
+    lv_img = (2.0 * torch.log(sg_bc[:B])).reshape(1, H, W, C).contiguous()
+    res = {}
+
+    def img_dev():
+        res["o"] = q.compress_latents(m_img, lv_img, lams, return_np=False)
+    for _ in range(warmup):
+        img_dev()
+    clock_ramp(torch, img_dev, min(RAMP_S, 0.15))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5 * steps):
+        img_dev()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / (5 * steps) * 1e3
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        img_dev()
+        torch.cuda.synchronize()
+    ms_sync = (time.perf_counter() - t0) / steps * 1e3
+    # its kernels one by one (events; each repeated alone): exp, planes, solve, fused lookups
+    var = torch.exp(lv_img).reshape(B, C)
+    ll_d, md_d = q._level_len_dev(lams), q._models_dev(lams)
+    tab_d, srt_d = q._table_dev(), q._sorted_dev()
+    mu_p, sg_p = ops.prep_planes(m_img.reshape(B, C), var, spread_is_variance=True)
+    idx_p = torch.empty((L, C, B), dtype=torch.uint16, device=dev)
+    k_exp = event_ms(torch, lambda: torch.exp(lv_img), 50, 5)
+    k_prep = event_ms(torch, lambda: ops.prep_planes(m_img.reshape(B, C), var, spread_is_variance=True, out_mu=mu_p, out_sigma=sg_p), 50, 5)
+    k_solve = event_ms(torch, lambda: ops.quantize(mu_p, sg_p, tab_d, lams, N=N_BITS, level_len=ll_d, layout="cb", out_idx=idx_p), 50, 5)
+    k_gather = event_ms(torch, lambda: ops.gather_latents(idx_p, N=N_BITS, table_sorted=srt_d, level_len=ll_d, models=md_d, want_num_bits=True), 50, 5)
+    kernels = k_exp + k_prep + k_solve + k_gather
+    # parity: the oracle's indices for this image (sigma as the device derived it) pushed through the same tables
+    sg_img_h = sg_p.t().contiguous().cpu().numpy()
+    ll_h = ll_d.cpu().numpy()
+    wi = CO.quantize(mu_h[:B], sg_img_h, tab_h, lams, N=N_BITS, level_len=ll_h, threads=CO.max_threads()).astype(np.int64)   # [L, B, C]
+    srt_h = np.sort(tab_h, axis=1)
+    ch = np.arange(C)[None, None, :]
+    ls = np.arange(L)[:, None, None]
+    lev = O.levels_of_sorted_ranks(N_BITS)[wi]
+    md_h = md_d.cpu().numpy()
+    o = res["o"]
+    ok = all(np.array_equal(o["Z_hat"][l].cpu().numpy().reshape(B, C), srt_h[ch[0], wi[i]]) and
+             np.array_equal(o["raw_num_bits"][l].cpu().numpy().reshape(B, C), ll_h[i][ch[0], lev[i]]) and
+             np.array_equal(o["num_bits"][l].cpu().numpy().reshape(B, C), md_h[i][ch[0], wi[i]]) for i, l in enumerate(lams))
+    alg = B * C * (8 + 12 * L)                                   # 8 B in per element, three f32 results per (element, lambda)
+    out["compress_latents_image"] = {
+        "ms_per_step": ms, "value": B * C * L / (ms * 1e-3), "unit": "latents/s",
+        "roofline": {"bound": "hbm", "kernel": "exp + k_prep_planes + k_quant_fast + k_gather_latents", "achieved": alg / (ms * 1e-3) / 1e9,
+                     "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": alg / (ms * 1e-3) / HBM_PEAK, "algorithmic_bytes_per_launch": alg,
+                     "avg_launch_ms": ms},
+        "ms_per_call_synchronised": ms_sync, "kernels_ms": {"exp": k_exp, "prep_planes": k_prep, "solve": k_solve, "gather_latents": k_gather},
+        "sum_of_kernels_ms": kernels, "call_over_sum_of_kernels": ms / kernels, "launches_per_call": 4,
+        "parity_vs_oracle_on_sample": bool(ok),
+        "workload": f"one Kodak image [1, {H}, {W}, {C}]: ChannelwisePriorCDFQuantizer.compress_latents(means, logvars, {L} lambdas of "
+                    f"post_process.py:115, return_np=False) with corrected lengths and entropy models on the device; {5 * steps} calls, one synchronisation"}
+    # the reference's own form: NumPy in, NumPy out (PCIe-bound: 3 x L x B x C x 4 B back per call) -- never the headline
+    m_np, lv_np = m_img.cpu().numpy(), lv_img.cpu().numpy()
+    for _ in range(2):
+        o_np = q.compress_latents(m_np, lv_np, lams)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        o_np = q.compress_latents(m_np, lv_np, lams)
+    ms_np = (time.perf_counter() - t0) / steps * 1e3
+    ok_np = all(np.array_equal(o_np[k][l], o[k][l].cpu().numpy()) for k in ("Z_hat", "raw_num_bits", "num_bits") for l in lams)
+    out["compress_latents_image_numpy"] = {
+        "ms_per_step": ms_np, "value": B * C * L / (ms_np * 1e-3), "unit": "latents/s",
+        "roofline": {"bound": "pcie", "kernel": "host copies", "frac": None, "bytes_to_host_per_call": 3 * L * B * C * 4},
+        "parity_vs_oracle_on_sample": bool(ok and ok_np),
+        "workload": f"the same call with NumPy arrays in and out (the reference's form, return_np=True): {3 * L * B * C * 4 / 1e6:.0f} MB "
+                    "to the host per call through the pinned staging block"}
     return out
 
 
