@@ -76,6 +76,14 @@ enum {
 int vbq_abi_version(void);
 const char *vbq_last_error(void);
 
+/* Process-wide launch policy for builds that overlap a collective with the kernels (the rank histogram's all-reduce
+ * of step i runs while step i + 1 computes).  The solve kernels run as RESIDENT grids sized to every workgroup slot of the
+ * chip; a collective's kernel (RCCL: a few dozen workgroups) takes some of those slots, and a resident workgroup that finds its
+ * slot taken starts only after another one has finished all its iterations -- up to twice the kernel time.  With n > 0 the
+ * grids are sized to (slots - n), or launched as short-lived workgroups when the (workgroups x channels) grid shape would
+ * give up more than a tenth of the chip.  n = 0 (default): every slot.  Also preset by VBQ_RESERVED_WORKGROUPS. */
+int vbq_set_reserved_workgroups(int32_t n);
+
 /* Number of GPUs visible / name of device `dev` (for harness output only). */
 int vbq_device_count(void);
 int vbq_device_name(int dev, char *buf, size_t buflen);

@@ -653,7 +653,8 @@ def test_prep_planes_is_transpose_and_exact_sqrt(rows, cols):
     assert torch.equal(m2, m_p) and torch.equal(s2, var.t().contiguous())
 
 
-@pytest.mark.parametrize("L,C,B,with_len", [(3, 70, 77, False), (2, 1, 1000, True), (5, 64, 32, True), (1, 130, 33, False)])
+@pytest.mark.parametrize("L,C,B,with_len", [(3, 70, 77, False), (2, 1, 1000, True), (5, 64, 32, True), (1, 130, 33, False),
+                                             (3, 128, 136, False), (2, 68, 200, True), (16, 256, 1536, True)])
 def test_gather_latents_one_pass_against_numpy(L, C, B, with_len):
     """vbq_gather_latents_u16: Z_hat, raw_num_bits, num_bits and the indices themselves, channel-last, from index planes in
     one pass -- against NumPy fancy indexing; ragged tiles, foreign indices >= T clamped like vbq_gather_f32."""

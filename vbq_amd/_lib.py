@@ -22,6 +22,7 @@ COMM_ID_BYTES = 128
 SIGNATURES = {
     "vbq_abi_version": (C.c_int, []),
     "vbq_last_error": (C.c_char_p, []),
+    "vbq_set_reserved_workgroups": (C.c_int, [C.c_int32]),
     "vbq_device_count": (C.c_int, []),
     "vbq_device_name": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t]),
     "vbq_quantize_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),

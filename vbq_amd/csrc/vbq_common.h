@@ -13,6 +13,10 @@ void set_error(const char *fmt, ...);
 // Compute units of the current device (hipDeviceProp_t::multiProcessorCount, cached per device): what the persistent
 // grids are sized by.  256 on MI355X; never hard-coded.
 int num_cus();
+// Workgroup slots of a resident grid with `per_cu` workgroups per CU, minus the slots reserved for a kernel of another stream
+// (vbq_set_reserved_workgroups: the distributed pipeline's overlapped all-reduce), never below one per CU.
+int64_t resident_slots(int per_cu);
+int reserved_workgroups();
 
 #define VBQ_REQUIRE(cond, code, ...)            \
     do {                                        \

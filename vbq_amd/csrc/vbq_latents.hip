@@ -12,6 +12,8 @@
 //
 // The level of rank index q is N - ctz(q + 1) (slot (n, i) <-> rank (2i + 1) 2^(N-n) - 1), so no per-rank length table is
 // built or read.
+#include <stdlib.h>
+
 #include "vbq_common.h"
 
 namespace vbq {
@@ -121,18 +123,120 @@ k_gather_latents(const uint16_t *__restrict__ idx, long B, int C, const float *_
     }
 }
 
+// The same with 16-byte accesses on both sides (B a multiple of 8, C a multiple of 4, 16-byte aligned pointers): tile = 64
+// channels x 64 rows; a thread reads two runs of 8 consecutive indices of one channel, issues all its table lookups at once
+// (up to 48 independent loads in flight: the lookups are latency-bound, the tables sit in L2), and the outputs go through ONE
+// LDS tile, one after the other, leaving as 16-byte stores of 4 consecutive channels.  The one-tile form keeps the LDS at
+// 17 KB per workgroup so that enough waves are resident to cover the lookups (a tile per output: 58 KB, 2 workgroups per CU).
+template <int N>
+__global__ void __launch_bounds__(256)
+k_gather_latents_vec(const uint16_t *__restrict__ idx, long B, int C, const float *__restrict__ tab_sorted,
+                     const float *__restrict__ level_len, const float *__restrict__ models, float *__restrict__ out_z,
+                     float *__restrict__ out_raw, int raw_as_int, float *__restrict__ out_nb, uint16_t *__restrict__ out_idx) {
+    constexpr int T = table_size(N), N1 = N + 1;
+    __shared__ float tile[64][65];
+    const int l = blockIdx.y;
+    const long ctiles = (C + 63) / 64;
+    const long r0 = ((long)blockIdx.x / ctiles) * 64;
+    const int c0 = (int)((long)blockIdx.x % ctiles) * 64;
+    const long E = B * (long)C;
+    int q[2][8];
+    bool live[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int v = threadIdx.x + 256 * k, lc = v >> 3, rg = (v & 7) * 8;
+        const int c = c0 + lc;
+        const long r = r0 + rg;
+        live[k] = c < C && r < B;                               // B % 8 == 0: a run of 8 rows is inside or outside as a whole
+        uint4 w = make_uint4(0, 0, 0, 0);
+        if (live[k]) w = *reinterpret_cast<const uint4 *>(idx + ((long)l * C + c) * B + r);
+        const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) q[k][j] = min((int)((ww[j >> 1] >> (16 * (j & 1))) & 0xffffu), T - 1);
+    }
+    float vz[2][8], vr[2][8], vn[2][8];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int v = threadIdx.x + 256 * k, lc = v >> 3;
+        const int c = min(c0 + lc, C - 1);
+        const float *ts = tab_sorted + (long)c * T;
+        const float *ll = level_len + ((long)l * C + c) * N1;
+        const float *mm = models + ((long)l * C + c) * T;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int lvl = N - __builtin_ctz((unsigned)q[k][j] + 1u);
+            if (out_z) vz[k][j] = ts[q[k][j]];
+            if (out_raw) vr[k][j] = level_len ? ll[lvl] : (raw_as_int ? __int_as_float(lvl) : (float)lvl);
+            if (out_nb) vn[k][j] = mm[q[k][j]];
+        }
+    }
+    auto emit = [&](const float (&val)[2][8], float *__restrict__ out) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int v = threadIdx.x + 256 * k, lc = v >> 3, rg = (v & 7) * 8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) tile[lc][rg + j] = val[k][j];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int v = threadIdx.x + 256 * k, lr = v >> 4, lc = (v & 15) * 4;       // 16 float4 per output row
+            const long r = r0 + lr;
+            const int c = c0 + lc;
+            if (r < B && c < C)                                 // C % 4 == 0: 4 channels are inside or outside as a whole
+                *reinterpret_cast<float4 *>(out + (long)l * E + r * C + c) =
+                    make_float4(tile[lc][lr], tile[lc + 1][lr], tile[lc + 2][lr], tile[lc + 3][lr]);
+        }
+        __syncthreads();
+    };
+    if (out_z) emit(vz, out_z);
+    if (out_raw) emit(vr, out_raw);
+    if (out_nb) emit(vn, out_nb);
+    if (out_idx) {
+        uint16_t *t16 = reinterpret_cast<uint16_t *>(&tile[0][0]);                     // [64][66] u16 inside the same block
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int v = threadIdx.x + 256 * k, lc = v >> 3, rg = (v & 7) * 8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t16[lc * 66 + rg + j] = (uint16_t)q[k][j];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int v = threadIdx.x + 256 * k, lr = v >> 4, lc = (v & 15) * 4;
+            const long r = r0 + lr;
+            const int c = c0 + lc;
+            if (r < B && c < C) {
+                uint2 w;
+                w.x = (uint32_t)t16[lc * 66 + lr] | ((uint32_t)t16[(lc + 1) * 66 + lr] << 16);
+                w.y = (uint32_t)t16[(lc + 2) * 66 + lr] | ((uint32_t)t16[(lc + 3) * 66 + lr] << 16);
+                *reinterpret_cast<uint2 *>(out_idx + (long)l * E + r * C + c) = w;
+            }
+        }
+    }
+    (void)live;
+}
+
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 int gather_latents(const uint16_t *idx, int64_t B, int32_t C, int32_t L, int32_t N, const float *tab_sorted, const float *level_len,
                    const float *models, float *out_z, void *out_raw, float *out_nb, uint16_t *out_idx, hipStream_t st) {
-    const int64_t tiles = ((B + kGlRows - 1) / kGlRows) * ((C + kGlCh - 1) / kGlCh);
+    const uintptr_t all = reinterpret_cast<uintptr_t>(idx) | reinterpret_cast<uintptr_t>(out_z) | reinterpret_cast<uintptr_t>(out_raw) |
+                          reinterpret_cast<uintptr_t>(out_nb) | reinterpret_cast<uintptr_t>(out_idx);
+    static const bool scalar_only = [] { const char *e = getenv("VBQ_GATHER_SCALAR"); return e && e[0] == '1'; }();   // A/B timing
+    const bool vec = !scalar_only && B % 8 == 0 && C % 4 == 0 && (all & 15) == 0;
+    const int64_t tiles = vec ? ((B + 63) / 64) * ((C + 63) / 64) : ((B + kGlRows - 1) / kGlRows) * ((C + kGlCh - 1) / kGlCh);
     VBQ_REQUIRE(tiles <= 0x7fffffffll && L <= 65535, VBQ_ERR_UNSUPPORTED, "vbq_gather_latents_u16: grid too large");
     const dim3 grid((unsigned)tiles, (unsigned)L);
     const int raw_as_int = level_len == nullptr;
 #define VBQ_DISPATCH_N(NN)                                                                                                  \
     case NN:                                                                                                                \
-        hipLaunchKernelGGL((k_gather_latents<NN>), grid, dim3(256), 0, st, idx, (long)B, (int)C, tab_sorted, level_len, models, \
-                           out_z, static_cast<float *>(out_raw), raw_as_int, out_nb, out_idx);                              \
+        if (vec)                                                                                                            \
+            hipLaunchKernelGGL((k_gather_latents_vec<NN>), grid, dim3(256), 0, st, idx, (long)B, (int)C, tab_sorted, level_len, \
+                               models, out_z, static_cast<float *>(out_raw), raw_as_int, out_nb, out_idx);                  \
+        else                                                                                                                \
+            hipLaunchKernelGGL((k_gather_latents<NN>), grid, dim3(256), 0, st, idx, (long)B, (int)C, tab_sorted, level_len, \
+                               models, out_z, static_cast<float *>(out_raw), raw_as_int, out_nb, out_idx);                  \
         break;
     switch (N) {
         VBQ_FOR_EACH_N(VBQ_DISPATCH_N)

@@ -1392,11 +1392,23 @@ int launch_quant_fast(const float *mu, const float *sg, int64_t n_per_ch, int64_
     // for 18 short-lived workgroups per channel and 394 us for the same resident grid without the rotation.
     // wg_per_cu < 4 leaves LDS and wave slots for a kernel of another stream (K2 overlapping this launch); 5 is taken as 4
     // (a fifth workgroup per CU would only wait for a slot: 444 us).
-    static const bool dynamic_grid = [] { const char *e = getenv("VBQ_K1_DYNAMIC"); return e && e[0] == '1'; }();   // A/B switch
+    static const bool dynamic_env = [] { const char *e = getenv("VBQ_K1_DYNAMIC"); return e && e[0] == '1'; }();   // A/B switch
     const bool explicit_wgs = wg_per_cu >= 1 && wg_per_cu <= 5;
     const int fit = kFastNE == 4 ? 3 : 4;
+    // Slots reserved for a kernel of another stream (vbq_set_reserved_workgroups: the overlapped all-reduce of a sharded build).
+    // A resident workgroup that finds its slot taken starts only when another one has FINISHED ALL its iterations -- up to twice
+    // the kernel time (EXPERIMENTS.md, "resident grids beside a collective") -- so the grid is sized to the slots that are left;
+    // the grid is (workgroups per channel) x channels, so with many channels that costs whole rounds of n_ch slots: when more
+    // than a tenth of the chip would be given up the launch falls back to short-lived workgroups, which lose 8 % alone but
+    // only their share of the taken slots beside a collective.
+    bool dynamic_grid = dynamic_env;
+    if (!dynamic_grid && !explicit_wgs && reserved_workgroups() > 0) {
+        const int64_t all = (int64_t)num_cus() * fit;
+        const int64_t kept = (resident_slots(fit) / n_ch) * n_ch;
+        if (kept * 10 < all * 9) dynamic_grid = true;
+    }
     const int per_cu = explicit_wgs ? (wg_per_cu < fit ? wg_per_cu : fit) : (dynamic_grid ? 5 : fit);
-    int64_t cap = (int64_t)num_cus() * per_cu * (!explicit_wgs && dynamic_grid ? 4 : 1) / n_ch;
+    int64_t cap = (dynamic_grid && !explicit_wgs ? (int64_t)num_cus() * per_cu * 4 : resident_slots(per_cu)) / n_ch;
     const bool resident = !(dynamic_grid && !explicit_wgs) && (int64_t)n_ch <= (int64_t)num_cus() * per_cu;
     if (resident) vec_ok |= 4;
     if (cap < 1) cap = 1;
@@ -1518,8 +1530,17 @@ int launch_level_counts_hull10(const float *mu, const float *sg, int64_t n_per_c
     if (!build_hull_sweep(lam, L, sw)) return 1;
     const int64_t nquads = (n_per_ch + VBQ_HULL_NE - 1) / VBQ_HULL_NE;
     int64_t gx = (nquads + kHullThreads - 1) / kHullThreads;
-    constexpr int rounds = 1;                               // grid = this many times the resident workgroups (measured)
-    int64_t cap = (int64_t)num_cus() * VBQ_HULL_WAVES * rounds * 256 / kHullThreads / n_ch;    // VBQ_HULL_WAVES x 4 waves per CU resident
+    // grid = the resident workgroups, one round (measured); with slots reserved for another stream's kernel (see
+    // launch_quant_fast) the grid shrinks to what is left, or -- when whole rounds of n_ch slots would go -- four rounds of
+    // short-lived workgroups
+    constexpr int per_cu = VBQ_HULL_WAVES * 256 / kHullThreads;
+    int rounds = 1;
+    int64_t slots = resident_slots(per_cu);
+    if (reserved_workgroups() > 0 && (slots / n_ch) * n_ch * 10 < (int64_t)num_cus() * per_cu * 9) {
+        rounds = 4;
+        slots = (int64_t)num_cus() * per_cu;
+    }
+    int64_t cap = slots * rounds / n_ch;                    // VBQ_HULL_WAVES x 4 waves per CU resident
     if (cap < 1) cap = 1;
     if (gx > cap) {
         // All `cap` workgroups are resident at once and the kernel is latency-bound, so what counts is the number of
