@@ -310,9 +310,9 @@ def headline(full, side_file=None):
                              "isolated_ms": _sig(ar.get("rank_histogram_allreduce_ms_isolated"), 4),
                              "ms_per_step_without_collectives": _sig(ar.get("ms_per_step_without_collectives"), 4),
                              "exposed_ms_per_step": _sig(ar.get("exposed_ms_per_step"), 4)}
-    if full.get("per_gpu"):                                  # [k1t ms, k1 ms, k2 ms, K1 HBM fraction] per rank
+    if full.get("per_gpu"):          # [k1t ms, k1 ms, k2 ms, K1 HBM fraction, k1 ms in the steps without collectives] per rank
         line["per_gpu"] = [[_sig(g.get("pass1_k1t_ms"), 4), _sig(g.get("pass2_k1_ms"), 4), _sig(g.get("pass2_k2_ms"), 4),
-                            _sig(g.get("k1_hbm_frac"), 3)] for g in full["per_gpu"]]
+                            _sig(g.get("k1_hbm_frac"), 3), _sig(g.get("pass2_k1_ms_without_collectives"), 4)] for g in full["per_gpu"]]
     if full.get("workloads"):                                # name: [ms_per_step, HBM fraction of its dominant kernel, parity]
         line["workloads"] = {k: [_sig(v.get("ms_per_step"), 4), _sig((v.get("roofline") or {}).get("frac"), 3),
                                  v.get("parity_ok", v.get("parity_vs_oracle_on_sample"))] for k, v in full["workloads"].items()}
@@ -565,7 +565,12 @@ def run_workload(name, args, torch, dist, dev, rank, world, steps, warmup, detai
         build.collectives = False
         for _ in range(2):
             step()
-        dt0 = timed(max(3, steps // 3)) / max(3, steps // 3)
+        timers0 = Timers(torch)
+        timers0.enabled = True
+        build.timers = timers0
+        n0 = max(3, steps // 3)
+        dt0 = timed(n0) / n0
+        build.timers = timers
         build.collectives = True
         torch.cuda.synchronize()
         reps = 5
@@ -586,6 +591,7 @@ def run_workload(name, args, torch, dist, dev, rank, world, steps, warmup, detai
                             "rank_histogram_allreduce_ms_isolated": ar * 1e3,
                             "ms_per_step_without_collectives": dt0 * 1e3,
                             "exposed_ms_per_step": max(0.0, dt / steps - dt0) * 1e3,
+                            "reserved_workgroups": build.reserved_workgroups,
                             "overlap": "asynchronous, two buffers: step i's rank histogram is reduced while step i+1 computes; "
                                        "the bit-length histogram has its own communicator"}
         # one last step with the collectives on, so that the buffers checked below hold GLOBAL histograms
@@ -594,6 +600,12 @@ def run_workload(name, args, torch, dist, dev, rank, world, steps, warmup, detai
         torch.cuda.synchronize()
         # every rank's own timers (configs[4]: "per-GPU roofline report")
         mine = {"rank": rank, "elements": E, "pass1_k1t_ms": k1h_ms, "pass2_k1_ms": k1_ms, "pass2_k2_ms": k2_ms,
+                # the same kernels in the steps run WITHOUT the collectives (every slot of the chip theirs): what the all-reduce
+                # beside them costs the kernels themselves, per rank
+                "pass1_k1t_ms_without_collectives": timers0.total_ms("k1h") / n0,
+                "pass2_k1_ms_without_collectives": timers0.total_ms("k1") / n0,
+                "pass2_k2_ms_without_collectives": timers0.total_ms("k2") / n0,
+                "reserved_workgroups": build.reserved_workgroups,
                 "layout_change_ms": timers.total_ms("layout") / steps if C > 1 else None,
                 "k1_hbm_frac": alg_bytes / (k1_ms * 1e-3) / HBM_PEAK, "k1t_hbm_frac": 8.0 * E / (k1h_ms * 1e-3) / HBM_PEAK,
                 "k2_hbm_frac": 2.0 * L * E / (k2_ms * 1e-3) / HBM_PEAK,

@@ -330,6 +330,7 @@ def test_bench_two_ranks_code_path(tmp_path):
     ar = d["allreduce"]
     assert ar["packed_3x21"] is True and ar["rank_histogram_payload_bytes"] == ((32 * 32 * 2047 + 2) // 3 + 1) * 8
     assert ar["rank_histogram_allreduce_ms_isolated"] > 0 and ar["ms_per_step_without_collectives"] > 0
+    assert ar["reserved_workgroups"] == 64            # 5.6 MB beside the next step's kernels: slots are left for the collective
     assert d["config"]["elements_per_gpu"] == 36864 * 32
     assert d["pairs_per_step"] == 2 * 36864 * 32 * 32                      # both ranks' pairs, counted once
     assert d["value"] == pytest.approx(d["pairs_per_step"] / (d["ms_per_step"] * 1e-3), rel=1e-6)
@@ -341,6 +342,7 @@ def test_bench_two_ranks_code_path(tmp_path):
         assert par[key] is True, key
     pg = d["per_gpu"]
     assert [g["rank"] for g in pg] == [0, 1] and all(g["pass2_k1_ms"] > 0 and 0 < g["k1_hbm_frac"] < 1 for g in pg)
+    assert all(g["pass2_k1_ms_without_collectives"] > 0 and g["pass1_k1t_ms_without_collectives"] > 0 for g in pg)
     assert len(d["rd_curve"]["lagrangian_per_latent"]) == 32 and d["rd_curve"]["vs_oracle_on_sample"]["max_rel_diff"] <= 1e-5
 
 

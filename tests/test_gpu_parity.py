@@ -425,3 +425,36 @@ def test_notebook_one_beta_negative_or_zero(ops):
             v, slot = CO.compress_coordinates(means, stds, b, pts, lens, threads=8)
             assert np.array_equal(host(val)[i], v), betas
             assert np.array_equal(host(idx)[i].astype(np.int64), rank_of_slot[slot]), betas
+
+
+def test_reserved_workgroups_change_the_grid_not_the_results(ops):
+    """vbq_set_reserved_workgroups (the launch policy beside an overlapped collective): K1 / K1t with slots left free -- a
+    smaller resident grid for few channels, short-lived workgroups for many -- give the same indices and counts."""
+    from vbq_amd import _lib
+    h = _lib.lib()
+    rng = np.random.default_rng(77)
+    lam = [float(v) for v in 2.0 ** np.linspace(-8, 7.5, 32)]
+    try:
+        for rows, C in ((300_000, 1), (9000, 64), (2100, 256)):
+            s_c = np.exp(rng.uniform(np.log(0.3), np.log(3.0), C))
+            mu = (rng.standard_normal((C, rows)) * s_c[:, None]).astype(np.float32)
+            sg = np.exp(rng.normal(-2, 0.7, (C, rows))).astype(np.float32)
+            tab = gaussian_tables(s_c) if "gaussian_tables" in globals() else None
+            if tab is None:
+                from scipy.stats import norm
+                xi = np.concatenate([(np.arange(2 ** k) + 0.5) / 2 ** k for k in range(N + 1)])
+                tab = norm.ppf(xi[None, :], scale=s_c[:, None]).astype(np.float32)
+            ll = (np.arange(N + 1, dtype=np.float32) + np.abs(rng.normal(0, 1, (32, C, N + 1)))).astype(np.float32)
+            got = {}
+            for r in (0, 64, 100000):
+                assert h.vbq_set_reserved_workgroups(r) == 0
+                idx = ops.quantize(dev(mu), dev(sg), dev(tab), lam, N=N, level_len=dev(ll), layout="cb")
+                lc = ops.level_counts(dev(mu), dev(sg), dev(tab), lam, N=N, layout="cb")
+                got[r] = (host(idx), host(lc))
+            want = CO.quantize(np.ascontiguousarray(mu.T), np.ascontiguousarray(sg.T), tab, lam, N=N, level_len=ll)
+            assert np.array_equal(got[0][0].transpose(0, 2, 1), want)
+            for r in (64, 100000):
+                assert np.array_equal(got[r][0], got[0][0]) and np.array_equal(got[r][1], got[0][1]), (rows, C, r)
+        assert h.vbq_set_reserved_workgroups(-1) != 0
+    finally:
+        h.vbq_set_reserved_workgroups(0)

@@ -222,7 +222,7 @@ def test_bench_headline_line_is_compact_and_complete(tmp_path, capsys):
     for k in ("value", "unit", "cores", "kind"):
         assert k in line["cpu_baseline"], k
     assert all(len(v) == 3 for v in line["workloads"].values()) and len(line["workloads"]) == len(full["workloads"])
-    assert len(line["per_gpu"]) == 8 and all(len(g) == 4 for g in line["per_gpu"])
+    assert len(line["per_gpu"]) == 8 and all(len(g) == 5 for g in line["per_gpu"])
     assert json.load(open(side))["rd_curve"]["lambda"] == pytest.approx(full["rd_curve"]["lambda"], rel=1e-6)
     # a record that would still be too long sheds its optional parts instead of outgrowing the parser
     full["workloads"] = {f"w{i}_" + "x" * 40: v for i, v in enumerate(list(full["workloads"].values()) * 8)}

@@ -1530,16 +1530,14 @@ int launch_level_counts_hull10(const float *mu, const float *sg, int64_t n_per_c
     if (!build_hull_sweep(lam, L, sw)) return 1;
     const int64_t nquads = (n_per_ch + VBQ_HULL_NE - 1) / VBQ_HULL_NE;
     int64_t gx = (nquads + kHullThreads - 1) / kHullThreads;
-    // grid = the resident workgroups, one round (measured); with slots reserved for another stream's kernel (see
-    // launch_quant_fast) the grid shrinks to what is left, or -- when whole rounds of n_ch slots would go -- four rounds of
-    // short-lived workgroups
+    // grid = the resident workgroups, one round (measured).  With slots reserved for another stream's kernel (see
+    // launch_quant_fast) the grid shrinks to what is left when the (workgroups x channels) shape allows it without giving up
+    // more than a tenth of the chip; otherwise it stays as it is: short-lived workgroups cost this kernel 32 % alone (156
+    // against 118 us) and gain 6 % beside a collective (EXPERIMENTS.md, "resident grids beside a collective").
     constexpr int per_cu = VBQ_HULL_WAVES * 256 / kHullThreads;
-    int rounds = 1;
+    constexpr int rounds = 1;
     int64_t slots = resident_slots(per_cu);
-    if (reserved_workgroups() > 0 && (slots / n_ch) * n_ch * 10 < (int64_t)num_cus() * per_cu * 9) {
-        rounds = 4;
-        slots = (int64_t)num_cus() * per_cu;
-    }
+    if ((slots / n_ch) * n_ch * 10 < (int64_t)num_cus() * per_cu * 9) slots = (int64_t)num_cus() * per_cu;
     int64_t cap = slots * rounds / n_ch;                    // VBQ_HULL_WAVES x 4 waves per CU resident
     if (cap < 1) cap = 1;
     if (gx > cap) {

@@ -122,7 +122,7 @@ class EntropyModelBuild:
     def __init__(self, rows: int, n_ch: int, lambdas: Sequence[float], table_lm: torch.Tensor, *, N: int = 10,
                  add_n_smoothing=1, global_rows: Optional[int] = None, distributed: bool = False, group=None,
                  level_group=None, n_chunks: Optional[int] = None, counts_dtype=None, keep_models: bool = True,
-                 buffers: Optional[dict] = None):
+                 buffers: Optional[dict] = None, reserved_workgroups: Optional[int] = None):
         """buffers: a dict the caller keeps between builds -- the index planes, the solve's workspace and the -log2 tables
         (device copies) of one shape are taken from it instead of being allocated / computed / uploaded again; every
         OUTPUT tensor (histograms, length table, models) is new per object."""
@@ -208,10 +208,29 @@ class EntropyModelBuild:
         if self.world > 1 and counts_dtype == torch.int32:
             from .dist import CountsAllReduce
             self.reducers = [CountsAllReduce(L * C * T, self.dev, max_global_count=self.global_rows, group=group) for _ in range(2)]
+        # Launch policy beside the overlapped all-reduce (vbq_set_reserved_workgroups; EXPERIMENTS.md, "resident grids beside a
+        # collective"): the solve kernels' resident grids assume every workgroup slot of the chip; with a collective's kernel
+        # holding some of them K1 takes 1.5 x as long (Kodak-24: 346 -> 530 us with as few as 8 slots taken) against 1.25 x
+        # when it leaves those slots alone or runs as short-lived workgroups -- which costs 4-5 % when nothing runs beside it.
+        # So: slots are reserved only when the rank histogram's all-reduce is long enough to sit beside the next step's kernels
+        # (megabytes: C > 1 builds); the 524 KB of a C = 1 build are over in tens of microseconds and every slot stays K1's.
+        if reserved_workgroups is None:
+            payload = 0
+            if self.world > 1:
+                r = self.reducers[0]
+                payload = r.payload_bytes(self.counts) if r is not None else self.counts.numel() * self.counts.element_size()
+            reserved_workgroups = 64 if payload >= (4 << 20) else 0
+        self.reserved_workgroups = int(reserved_workgroups)
 
     # ---------------------------------------------------------------- stages
+    def _set_launch_policy(self):
+        # process-wide in the library: set at the head of every pass (another build of this process may want another value)
+        ops._lib.check(ops._lib.lib().vbq_set_reserved_workgroups(self.reserved_workgroups if self.collectives else 0),
+                       "vbq_set_reserved_workgroups")
+
     def pass1(self, mu_cb, sg_cb, level_len=None):
         """quantizer.py:96-105.  level_len: the table of an earlier build, if any (the reference reuses it, :166)."""
+        self._set_launch_policy()
         self.level_counts.zero_()
         self._t("k1h", 0)
         ops.level_counts(mu_cb, sg_cb, self.table, self.lambdas, N=self.N, level_len=level_len, layout="cb",
@@ -243,6 +262,7 @@ class EntropyModelBuild:
             self._slot ^= 1
             self.counts = self._counts2[self._slot]
         self.wait(self._slot)                 # the all-reduce that last used this buffer
+        self._set_launch_policy()
         main = torch.cuda.current_stream(self.dev)
         self._models_current = False
         if self.side is None and self.world == 1:
