@@ -31,9 +31,11 @@ def main():
     ap.add_argument("--threads", type=int, default=512)
     ap.add_argument("--workload", default="kodak")
     ap.add_argument("--reps", type=int, default=12)
+    ap.add_argument("--counted", type=int, default=0, help="1: spin = counted s_sleep loop, 2: counted add loop (no s_memrealtime)")
     args = ap.parse_args()
     spin = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "bin", "libspin.so"))
     spin.spin_launch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_double]
+    spin.spin_launch_counted.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_double]
     dev = torch.device("cuda")
     rows, C = (36864, 256) if args.workload == "kodak" else (10_000_000, 1)
     mu_h, sg_h, tab_h = make_inputs(rows, C, 1000)
@@ -66,20 +68,30 @@ def main():
         res = {}
         for name, fn in kernels.items():
             torch.cuda.synchronize()
-            for _ in range(3):
-                fn()
-            torch.cuda.synchronize()
-            if k > 0:                                            # resident for the whole timed window
-                rc = spin.spin_launch(ctypes.c_void_p(side.cuda_stream), k, args.threads, 12.0)
+            if k > 0:                                            # resident for the ramp and the whole timed window
+                if args.counted:
+                    rc = spin.spin_launch_counted(ctypes.c_void_p(side.cuda_stream), k, args.counted, 60.0)
+                else:
+                    rc = spin.spin_launch(ctypes.c_void_p(side.cuda_stream), k, args.threads, 60.0)
                 assert rc == 0, rc
-                time.sleep(0.0005)
+            # the SAME untimed ramp with and without the neighbour: ~25 ms of back-to-back launches, no idle gap in front of
+            # the timed ones (an idle gap alone costs 10-50 %: the first version of this tool slept 0.5 ms after starting the
+            # spin kernel and blamed the neighbour for it)
+            t0 = time.perf_counter()
+            while time.perf_counter() - t0 < 0.025:
+                for _ in range(4):
+                    fn()
+                torch.cuda.current_stream().synchronize()        # this stream only: the neighbour keeps running
             evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.reps)]
             for a, b in evs:
                 a.record(); fn(); b.record()
+            torch.cuda.current_stream().synchronize()
+            still = not side.query() if k > 0 else None          # the neighbour must have outlived the timed launches
             torch.cuda.synchronize()
+            assert still is not False, "the spin kernel ended before the timed launches did"
             t = sorted(a.elapsed_time(b) for a, b in evs)
             res[name] = (t[len(t) // 2], t[0], t[-1])
-        print(f"{args.workload:6s} {policy:28s} k={k:3d} x {args.threads} threads: " +
+        print(f"{args.workload:6s} {policy:28s} k={k:3d} x {args.threads if not args.counted else 64} threads{' (counted ' + ('sleep' if args.counted == 1 else 'adds') + ')' if args.counted else ''}: " +
               "  ".join(f"{n} {m * 1e3:7.1f} us (min {lo * 1e3:.1f}, max {hi * 1e3:.1f})" for n, (m, lo, hi) in res.items()), flush=True)
 
 
