@@ -295,6 +295,26 @@ def test_integration_md_sequence_through_ctypes_only():
         assert np.array_equal(raw_models[i].cpu().numpy(), orc.raw_models[k])
         assert np.array_equal(models[i].cpu().numpy(), orc.entropy_models[k])
     assert int(counts.sum().item()) == L * Cc * B
+    # ... and INTEGRATION.md's per-image call on top of the tables the build left on the device: one C call
+    Bi = 768                                                       # one "image" of 768 positions, channel-last as it arrives
+    means = torch.from_numpy(mu_h[:Bi]).to(dev_)
+    var = torch.from_numpy(sg_h[:Bi]).to(dev_) ** 2
+    sig_dev = torch.sqrt(var).cpu().numpy()                        # what the call derives (IEEE root of the variance handed in)
+    table_sorted = torch.from_numpy(np.sort(tab_h, axis=1)).to(dev_)
+    z = torch.empty((L, Bi, Cc), dtype=torch.float32, device=dev_)
+    raw = torch.empty_like(z)
+    nb = torch.empty_like(z)
+    nws2 = h.vbq_compress_latents_workspace_bytes(Bi, Cc, L, N)
+    ws2 = torch.empty(nws2, dtype=torch.uint8, device=dev_)
+    assert h.vbq_compress_latents_f32(p(means), p(var), 1, Bi, Cc, p(table), p(table_sorted), p(level_len), p(models), lamc, L, N,
+                                      p(z), p(raw), p(nb), p(ws2), nws2, st) == 0
+    torch.cuda.synchronize()
+    ref = orc.compress_latents(mu_h[:Bi], sig_dev, keys)
+    for i, k in enumerate(keys):
+        assert np.array_equal(z[i].cpu().numpy(), ref["Z_hat"][k]) and np.array_equal(raw[i].cpu().numpy(), ref["raw_num_bits"][k])
+        assert np.array_equal(nb[i].cpu().numpy(), ref["num_bits"][k])
+    assert h.vbq_compress_latents_f32(p(means), p(var), 1, Bi, Cc, p(table), p(table_sorted), p(level_len), p(models), lamc, L, N,
+                                      p(z), p(raw), p(nb), p(ws2), nws2 - 1, st) != 0        # a short workspace is refused
 
 
 # ---------------------------------------------------------------------------------------------------------------------
