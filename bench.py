@@ -172,7 +172,7 @@ def committed_counters(workload, rows, C, L):
             pj = json.load(open(f))
             bl = pj.get("bench_line", {}).get("config", {})
             if bl.get("elements_per_gpu") == rows * C and bl.get("lambdas") == L and "k_quant_fast" in pj and \
-                    bl.get("workload", "").startswith(workload + ":") and "hbm_bytes_per_launch" in pj["k_quant_fast"]:
+                    bl.get("workload", "").startswith(workload) and "hbm_bytes_per_launch" in pj["k_quant_fast"]:
                 src = os.path.relpath(f, ROOT)
                 k = pj["k_quant_fast"]
                 sqc = k.get("sq", {})

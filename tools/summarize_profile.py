@@ -19,7 +19,7 @@ src = os.path.join(root, "gpurun_out")
 dst = os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
 
-KERNELS = ("k_level_counts_hull", "k_quant_hull_idx", "k_quant_pruned", "k_quant_fast", "k_transpose_batched", "k_rd_sums", "k_hist_flat", "k_transpose", "k_prepare_penalties", "k_quant_tiled",
+KERNELS = ("k_prep_planes", "k_gather_latents", "k_level_counts_hull", "k_quant_hull_idx", "k_quant_pruned", "k_quant_fast", "k_transpose_batched", "k_rd_sums", "k_hist_flat", "k_transpose", "k_prepare_penalties", "k_quant_tiled",
            "k_quant_flat", "k_gather", "k_hist_tiled", "k_quant_notebook", "k_lut_lengths", "k_lut_models", "k_np_block_sums")
 
 
@@ -41,6 +41,8 @@ def newest(pattern):
 
 stats = newest(os.path.join(src, f"{tag}_stats", "*", "*_kernel_stats.csv"))[0]
 shutil.copy(stats, os.path.join(dst, f"{tag}_kernel_stats.csv"))
+for f_all in newest(os.path.join(src, f"{tag}_all_stats", "*", "*_kernel_stats.csv")):
+    shutil.copy(f_all, os.path.join(dst, f"{tag}_all_workloads_kernel_stats.csv"))
 rows = list(csv.DictReader(open(stats)))
 pmc = collections.defaultdict(dict)
 for cname, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
@@ -117,6 +119,9 @@ for k, m in merged.items():
 bench = os.path.join(src, f"{tag}_bench_final.json")
 if not os.path.exists(bench):
     bench = os.path.join(src, f"{tag}_bench.json")
+full = os.path.join(src, f"{tag}_bench_full.json")           # the full record of the same run (the line itself is the compact form)
+if os.path.exists(full):
+    shutil.copy(full, os.path.join(dst, f"{tag}_bench_full.json"))
 if os.path.exists(bench):
     out["bench_line"] = json.loads(open(bench).read().strip().splitlines()[-1])
 json.dump(out, open(os.path.join(dst, f"{tag}_pmc.json"), "w"), indent=1)
