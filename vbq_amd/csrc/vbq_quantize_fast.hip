@@ -1532,12 +1532,15 @@ int launch_level_counts_hull10(const float *mu, const float *sg, int64_t n_per_c
     int64_t gx = (nquads + kHullThreads - 1) / kHullThreads;
     // grid = the resident workgroups, one round (measured).  With slots reserved for another stream's kernel (see
     // launch_quant_fast) the grid shrinks to what is left when the (workgroups x channels) shape allows it without giving up
-    // more than a tenth of the chip; otherwise it stays as it is: short-lived workgroups cost this kernel 32 % alone (156
-    // against 118 us) and gain 6 % beside a collective (EXPERIMENTS.md, "resident grids beside a collective").
+    // more than a tenth of the chip; otherwise it drops to three workgroups per CU: 129 us alone instead of 117, but 146-150
+    // instead of 172 beside a neighbour (short-lived workgroups: 156 alone, 172-178 beside one; two per CU: 160 either way --
+    // EXPERIMENTS.md, "resident grids beside a collective").
     constexpr int per_cu = VBQ_HULL_WAVES * 256 / kHullThreads;
     constexpr int rounds = 1;
     int64_t slots = resident_slots(per_cu);
-    if ((slots / n_ch) * n_ch * 10 < (int64_t)num_cus() * per_cu * 9) slots = (int64_t)num_cus() * per_cu;
+    if ((slots / n_ch) * n_ch * 10 < (int64_t)num_cus() * per_cu * 9) slots = (int64_t)num_cus() * (per_cu > 1 ? per_cu - 1 : 1);
+    static const int exp_per_cu = [] { const char *e = getenv("VBQ_HULL_WG_PER_CU"); return e ? atoi(e) : 0; }();   // A/B switch
+    if (exp_per_cu > 0 && exp_per_cu < per_cu) slots = (int64_t)num_cus() * exp_per_cu;
     int64_t cap = slots * rounds / n_ch;                    // VBQ_HULL_WAVES x 4 waves per CU resident
     if (cap < 1) cap = 1;
     if (gx > cap) {
