@@ -330,8 +330,10 @@ int vbq_transpose_planes(const void *d_in, int64_t n_batch, int64_t n_rows, int6
  *
  *   vbq_prep_planes_f32     channel-last latents [n_rows][n_ch] -> channel-major planes [n_ch][n_rows]
  *                           (the tf.transpose of quantizer.py:163-164,223), means and spreads in one launch;
- *                           spread_is_variance != 0: the spreads are exp(logvar) and sigma = sqrt(.) is taken
- *                           on the way (quantizer.py:197,202 `tf.exp(posterior_logvars) ** 0.5`; IEEE sqrt).
+ *                           spread_kind says what d_spread_bc holds: VBQ_SPREAD_SIGMA the standard deviations,
+ *                           VBQ_SPREAD_VARIANCE exp(logvar) (sigma = sqrt(.), IEEE), VBQ_SPREAD_LOGVAR the encoder's
+ *                           log-variances themselves (sigma = sqrt(exp(.)): quantizer.py:197,202
+ *                           `tf.exp(posterior_logvars) ** 0.5` inside the same launch).
  *   vbq_gather_latents_u16  ONE pass over rank indices in planes [n_lambda][n_ch][n_rows] writing, channel-last
  *                           [n_lambda][n_rows][n_ch] (any subset; NULL skips an output):
  *                             d_out_zhat      f32  d_table_sorted[c][q]                      quantizer.py:224-225
@@ -341,18 +343,19 @@ int vbq_transpose_planes(const void *d_in, int64_t n_batch, int64_t n_rows, int6
  *                             d_out_num_bits  f32  d_models[l][c][q] (entropy_models, by rank) quantizer.py:226-228
  *                             d_out_idx       u16  q itself (the index planes transposed)
  *   vbq_compress_latents_f32   prep -> vbq_quantize_f32 on planes (raw lengths when d_level_len is NULL) ->
- *                           gather.  d_spread_bc holds sigma, or exp(logvar) with spread_is_variance != 0.
+ *                           gather.  d_spread_bc as for vbq_prep_planes_f32 (spread_kind).
  *                           Workspace: vbq_compress_latents_workspace_bytes() bytes of device memory, 256-byte
  *                           aligned (the planes, the index planes and the solve's own workspace live there).
  * ---------------------------------------------------------------------------------- */
-int vbq_prep_planes_f32(const float *d_means_bc, const float *d_spread_bc, int32_t spread_is_variance, int64_t n_rows,
+enum { VBQ_SPREAD_SIGMA = 0, VBQ_SPREAD_VARIANCE = 1, VBQ_SPREAD_LOGVAR = 2 };
+int vbq_prep_planes_f32(const float *d_means_bc, const float *d_spread_bc, int32_t spread_kind, int64_t n_rows,
                         int32_t n_ch, float *d_mu_cb, float *d_sigma_cb, void *stream);
 int vbq_gather_latents_u16(const uint16_t *d_idx_planes, int64_t n_rows, int32_t n_ch, int32_t n_lambda, int32_t N,
                            const float *d_table_sorted, const float *d_level_len, const float *d_models,
                            float *d_out_zhat, void *d_out_raw_bits, float *d_out_num_bits, uint16_t *d_out_idx,
                            void *stream);
 size_t vbq_compress_latents_workspace_bytes(int64_t n_rows, int32_t n_ch, int32_t n_lambda, int32_t N);
-int vbq_compress_latents_f32(const float *d_means_bc, const float *d_spread_bc, int32_t spread_is_variance,
+int vbq_compress_latents_f32(const float *d_means_bc, const float *d_spread_bc, int32_t spread_kind,
                              int64_t n_rows, int32_t n_ch, const float *d_table_lm, const float *d_table_sorted,
                              const float *d_level_len, const float *d_models, const double *h_lambdas,
                              int32_t n_lambda, int32_t N, float *d_out_zhat, void *d_out_raw_bits,

@@ -638,19 +638,42 @@ def test_input_validation_is_available_and_off_by_default():
 
 @pytest.mark.parametrize("rows,cols", [(64, 64), (777, 24), (130, 3), (1, 1), (4096, 256)])
 def test_prep_planes_is_transpose_and_exact_sqrt(rows, cols):
-    """vbq_prep_planes_f32: both layout changes in one launch; with spread_is_variance the sigma plane is the IEEE square
-    root of exp(logvar) -- the very numbers torch's `exp(logvars) ** 0.5` gives (quantizer.py:197,202)."""
+    """vbq_prep_planes_f32: both layout changes in one launch; with spread='variance' the sigma plane is the IEEE square
+    root of exp(logvar), with spread='logvar' sqrt(exp(.)) of the log-variances themselves -- the very numbers torch's
+    `exp(logvars) ** 0.5` gives (quantizer.py:197,202)."""
     from vbq_amd import ops
     rng = np.random.default_rng(rows * 1000 + cols)
     mu = torch.from_numpy(rng.normal(0, 2, (rows, cols)).astype(np.float32)).cuda()
     lv = rng.normal(-4, 3, (rows, cols)).astype(np.float32)
     lv.reshape(-1)[:5] = [-200.0, 88.0, -87.5, 0.0, -103.0][: min(5, lv.size)]     # 0, near-overflow, denormal variances
     var = torch.exp(torch.from_numpy(lv).cuda())
-    m_p, s_p = ops.prep_planes(mu, var, spread_is_variance=True)
+    m_p, s_p = ops.prep_planes(mu, var, spread="variance")
+    m_l, s_l = ops.prep_planes(mu, torch.from_numpy(lv).cuda(), spread="logvar")
+    assert torch.equal(m_l, m_p) and torch.equal(s_l, s_p)
+    with pytest.raises(ValueError):
+        ops.prep_planes(mu, var, spread="stddev")
     assert torch.equal(m_p, mu.t().contiguous())
     assert torch.equal(s_p, (var ** 0.5).t().contiguous()) and torch.equal(s_p, torch.sqrt(var).t().contiguous())
     m2, s2 = ops.prep_planes(mu, var)
     assert torch.equal(m2, m_p) and torch.equal(s2, var.t().contiguous())
+
+
+@pytest.mark.timeout(600)
+def test_logvar_to_sigma_is_torchs_for_every_float32():
+    """compress_latents hands the encoder's log-variances to the planes kernel, which takes sigma = sqrtf(expf(.)) itself
+    (quantizer.py:197,202 `tf.exp(posterior_logvars) ** 0.5`).  That is only a drop-in for the torch ops it replaced if it is
+    the SAME function: checked here for every one of the 2^32 float32 bit patterns (NaNs compare as NaNs)."""
+    from vbq_amd import ops
+    dev_ = torch.device("cuda")
+    n = 1 << 26
+    for chunk in range(64):
+        bits = (torch.arange(chunk * n, (chunk + 1) * n, dtype=torch.int64, device=dev_) - ((1 << 32) if chunk >= 32 else 0)).to(torch.int32)
+        x = bits.view(torch.float32).reshape(n // 256, 256)
+        want = torch.exp(x) ** 0.5
+        got = ops.prep_planes(x, x, spread="logvar")[1].t()
+        differ = (got.view(torch.int32) != want.view(torch.int32)) & ~(torch.isnan(got) & torch.isnan(want))
+        assert not bool(differ.any()), f"chunk {chunk}: {int(differ.sum())} values differ from torch.exp(x) ** 0.5"
+        del bits, x, want, got, differ
 
 
 @pytest.mark.parametrize("L,C,B,with_len", [(3, 70, 77, False), (2, 1, 1000, True), (5, 64, 32, True), (1, 130, 33, False),

@@ -298,7 +298,7 @@ def test_integration_md_sequence_through_ctypes_only():
     # ... and INTEGRATION.md's per-image call on top of the tables the build left on the device: one C call
     Bi = 768                                                       # one "image" of 768 positions, channel-last as it arrives
     means = torch.from_numpy(mu_h[:Bi]).to(dev_)
-    var = torch.from_numpy(sg_h[:Bi]).to(dev_) ** 2
+    var = torch.from_numpy(sg_h[:Bi]).to(dev_) ** 2                # 1 = VBQ_SPREAD_VARIANCE below
     sig_dev = torch.sqrt(var).cpu().numpy()                        # what the call derives (IEEE root of the variance handed in)
     table_sorted = torch.from_numpy(np.sort(tab_h, axis=1)).to(dev_)
     z = torch.empty((L, Bi, Cc), dtype=torch.float32, device=dev_)

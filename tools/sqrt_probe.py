@@ -9,7 +9,7 @@ rng = np.random.default_rng(0)
 lv = rng.normal(-4, 3, (4096, 256)).astype(np.float32)
 lv.reshape(-1)[:6] = [-200.0, 88.0, -87.5, 0.0, -103.0, -95.0]
 var = torch.exp(torch.from_numpy(lv).cuda())
-mine = ops.prep_planes(var, var, spread_is_variance=True)[1].t().contiguous()
+mine = ops.prep_planes(var, var, spread="variance")[1].t().contiguous()
 p = var ** 0.5
 s = torch.sqrt(var)
 ref = torch.sqrt(var.double()).float()

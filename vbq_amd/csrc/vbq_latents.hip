@@ -2,8 +2,11 @@
 // img-compression/quantizer.py:190-240, called once per image by utils.py:542-554 -- as ONE C call and three launches:
 //
 //   k_prep_planes       channel-last means / spreads [B][C] -> channel-major planes [C][B] (quantizer.py:163-164,223),
-//                       with sigma = sqrt(variance) folded in when the caller hands exp(logvar) (quantizer.py:197,202:
-//                       `tf.exp(posterior_logvars) ** 0.5`; sqrt is correctly rounded, so it is the same number)
+//                       with sigma = sqrt(exp(logvar)) folded in when the caller hands the log-variances as they come out of
+//                       the encoder (quantizer.py:197,202: `tf.exp(posterior_logvars) ** 0.5`): sqrtf is the IEEE root
+//                       (__fsqrt_rn is NOT on gfx950) and expf is the device library's exp -- the numbers torch's
+//                       `exp(x) ** 0.5` gives on this device for every one of the 2^32 float32 inputs
+//                       (tests/test_gpu_api.py::test_logvar_to_sigma_is_torchs_for_every_float32)
 //   K1 / K1e / K1p      the solve on planes (vbq_quantize_f32)
 //   k_gather_latents    ONE pass over the rank indices [L][C][B]: Z_hat = sorted table[c][q]  (quantizer.py:224-225),
 //                       raw_num_bits = level(q) or level_len[l][c][level(q)] (:171-175,186-188), num_bits =
@@ -28,7 +31,8 @@ k_prep_planes(const float *__restrict__ in0, const float *__restrict__ in1, long
     const bool second = blockIdx.y == 1;
     const float *in = second ? in1 : in0;
     float *out = second ? out1 : out0;
-    const bool root = second && sqrt1;
+    const int kind = second ? sqrt1 : 0;                         // 0: copy, 1: sqrt(x), 2: sqrt(exp(x))
+    auto f = [kind](float x) { return kind == 0 ? x : sqrtf(kind == 2 ? expf(x) : x); };
     const long ctiles = (cols + 63) / 64;
     const long r0 = ((long)blockIdx.x / ctiles) * 64, c0 = ((long)blockIdx.x % ctiles) * 64;
     if (v4 && r0 + 64 <= rows && c0 + 64 <= cols) {
@@ -41,7 +45,7 @@ k_prep_planes(const float *__restrict__ in0, const float *__restrict__ in1, long
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int i = threadIdx.x + 256 * k, lr = i >> 4, lc = (i & 15) * 4;
-            if (root) { v[k].x = sqrtf(v[k].x); v[k].y = sqrtf(v[k].y); v[k].z = sqrtf(v[k].z); v[k].w = sqrtf(v[k].w); }
+            if (kind) { v[k].x = f(v[k].x); v[k].y = f(v[k].y); v[k].z = f(v[k].z); v[k].w = f(v[k].w); }
             tile[lr][lc] = v[k].x; tile[lr][lc + 1] = v[k].y; tile[lr][lc + 2] = v[k].z; tile[lr][lc + 3] = v[k].w;
         }
         __syncthreads();
@@ -59,7 +63,7 @@ k_prep_planes(const float *__restrict__ in0, const float *__restrict__ in1, long
         const long r = r0 + ty + 4 * k, c = c0 + tx;
         if (r < rows && c < cols) {
             const float x = in[r * cols + c];
-            tile[ty + 4 * k][tx] = root ? sqrtf(x) : x;
+            tile[ty + 4 * k][tx] = f(x);
         }
     }
     __syncthreads();
@@ -268,10 +272,12 @@ extern "C" int vbq_gather_latents_u16(const uint16_t *d_idx_planes, int64_t n_ro
                           d_out_num_bits, d_out_idx, reinterpret_cast<hipStream_t>(stream));
 }
 
-extern "C" int vbq_prep_planes_f32(const float *d_means_bc, const float *d_spread_bc, int32_t spread_is_variance, int64_t n_rows,
+extern "C" int vbq_prep_planes_f32(const float *d_means_bc, const float *d_spread_bc, int32_t spread_kind, int64_t n_rows,
                                    int32_t n_ch, float *d_mu_cb, float *d_sigma_cb, void *stream) {
     using namespace vbq;
     VBQ_REQUIRE(n_rows >= 0 && n_ch >= 1, VBQ_ERR_INVALID_ARGUMENT, "vbq_prep_planes_f32: bad sizes");
+    VBQ_REQUIRE(spread_kind >= VBQ_SPREAD_SIGMA && spread_kind <= VBQ_SPREAD_LOGVAR, VBQ_ERR_INVALID_ARGUMENT,
+                "vbq_prep_planes_f32: unknown spread_kind %d", spread_kind);
     if (n_rows == 0) return VBQ_OK;
     VBQ_REQUIRE(d_means_bc && d_spread_bc && d_mu_cb && d_sigma_cb && d_means_bc != d_mu_cb && d_spread_bc != d_sigma_cb,
                 VBQ_ERR_INVALID_ARGUMENT, "vbq_prep_planes_f32: null or aliased pointers");
@@ -281,7 +287,7 @@ extern "C" int vbq_prep_planes_f32(const float *d_means_bc, const float *d_sprea
                           reinterpret_cast<uintptr_t>(d_mu_cb) | reinterpret_cast<uintptr_t>(d_sigma_cb);
     const int v4 = n_rows % 4 == 0 && n_ch % 4 == 0 && (all & 15) == 0;
     hipLaunchKernelGGL(k_prep_planes, dim3((unsigned)tiles, 2), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), d_means_bc,
-                       d_spread_bc, (long)n_rows, (long)n_ch, d_mu_cb, d_sigma_cb, (int)(spread_is_variance != 0), v4);
+                       d_spread_bc, (long)n_rows, (long)n_ch, d_mu_cb, d_sigma_cb, (int)spread_kind, v4);
     VBQ_CHECK_LAUNCH("prep_planes");
     return VBQ_OK;
 }
@@ -293,7 +299,7 @@ extern "C" size_t vbq_compress_latents_workspace_bytes(int64_t n_rows, int32_t n
            vbq::align256(vbq_quantize_workspace_bytes(n_ch, n_lambda, N));
 }
 
-extern "C" int vbq_compress_latents_f32(const float *d_means_bc, const float *d_spread_bc, int32_t spread_is_variance,
+extern "C" int vbq_compress_latents_f32(const float *d_means_bc, const float *d_spread_bc, int32_t spread_kind,
                                         int64_t n_rows, int32_t n_ch, const float *d_table_lm, const float *d_table_sorted,
                                         const float *d_level_len, const float *d_models, const double *h_lambdas,
                                         int32_t n_lambda, int32_t N, float *d_out_zhat, void *d_out_raw_bits,
@@ -315,7 +321,7 @@ extern "C" int vbq_compress_latents_f32(const float *d_means_bc, const float *d_
     uint16_t *idx = reinterpret_cast<uint16_t *>(w);
     w += align256((size_t)n_lambda * E * sizeof(uint16_t));
     const size_t qws = vbq_quantize_workspace_bytes(n_ch, n_lambda, N);
-    int rc = vbq_prep_planes_f32(d_means_bc, d_spread_bc, spread_is_variance, n_rows, n_ch, mu_cb, sg_cb, stream);
+    int rc = vbq_prep_planes_f32(d_means_bc, d_spread_bc, spread_kind, n_rows, n_ch, mu_cb, sg_cb, stream);
     if (rc != VBQ_OK) return rc;
     rc = vbq_quantize_f32(mu_cb, sg_cb, n_rows, n_ch, VBQ_LAYOUT_CB, d_table_lm, d_level_len, h_lambdas, n_lambda, N, VBQ_MODE_F32,
                           idx, nullptr, nullptr, w, qws, stream);

@@ -337,10 +337,21 @@ def gather(idx: torch.Tensor, tab: torch.Tensor, n_ch: int, *, N: int = 10, layo
     return out
 
 
-def prep_planes(means_bc: torch.Tensor, spread_bc: torch.Tensor, *, spread_is_variance: bool = False,
+_SPREADS = {"sigma": 0, "variance": 1, "logvar": 2}
+
+
+def _spread_kind(spread: str) -> int:
+    try:
+        return _SPREADS[spread]
+    except KeyError:
+        raise ValueError(f"spread must be one of {sorted(_SPREADS)}, got {spread!r}") from None
+
+
+def prep_planes(means_bc: torch.Tensor, spread_bc: torch.Tensor, *, spread: str = "sigma",
                 out_mu: Optional[torch.Tensor] = None, out_sigma: Optional[torch.Tensor] = None):
-    """vbq_prep_planes_f32: channel-last [rows, C] means and spreads -> channel-major planes [C, rows] in ONE launch;
-    spread_is_variance: the spreads are exp(logvar), sigma = sqrt(.) is taken on the way (quantizer.py:197,202)."""
+    """vbq_prep_planes_f32: channel-last [rows, C] means and spreads -> channel-major planes [C, rows] in ONE launch.
+    spread: what `spread_bc` holds -- 'sigma', 'variance' (sigma = sqrt(.)) or 'logvar' (sigma = sqrt(exp(.)), the
+    `tf.exp(posterior_logvars) ** 0.5` of quantizer.py:197,202 inside the launch)."""
     means_bc = _dev(means_bc, torch.float32, "means")
     spread_bc = _dev(spread_bc, torch.float32, "spread")
     if means_bc.dim() != 2 or means_bc.shape != spread_bc.shape:
@@ -353,7 +364,7 @@ def prep_planes(means_bc: torch.Tensor, spread_bc: torch.Tensor, *, spread_is_va
         elif tuple(o.shape) != (c, r) or o.dtype != torch.float32 or not o.is_contiguous() or not o.is_cuda:
             raise ValueError(f"{name} must be a contiguous f32 device tensor of shape {(c, r)}")
         outs.append(o)
-    check(_lib.lib().vbq_prep_planes_f32(_ptr(means_bc), _ptr(spread_bc), int(bool(spread_is_variance)), r, c, _ptr(outs[0]),
+    check(_lib.lib().vbq_prep_planes_f32(_ptr(means_bc), _ptr(spread_bc), _spread_kind(spread), r, c, _ptr(outs[0]),
                                          _ptr(outs[1]), _stream(means_bc)), "vbq_prep_planes_f32")
     return outs[0], outs[1]
 
@@ -392,11 +403,12 @@ def gather_latents(idx_planes: torch.Tensor, *, N: int = 10, table_sorted: Optio
 
 
 def compress_latents(means_bc: torch.Tensor, spread_bc: torch.Tensor, table_lm: torch.Tensor, table_sorted: torch.Tensor,
-                     lambdas: Sequence[float], *, N: int = 10, spread_is_variance: bool = False,
+                     lambdas: Sequence[float], *, N: int = 10, spread: str = "sigma",
                      level_len: Optional[torch.Tensor] = None, models: Optional[torch.Tensor] = None,
                      workspace: Optional[torch.Tensor] = None):
     """vbq_compress_latents_f32: the per-image call of quantizer.py:190-240 in one C call (planes, solve, fused lookups).
-    means / spreads channel-last [B, C]; returns (Z_hat f32, raw_num_bits int32 | f32, num_bits f32 | None), [L, B, C]."""
+    means / spreads channel-last [B, C] (spread: 'sigma' | 'variance' | 'logvar', see prep_planes); returns
+    (Z_hat f32, raw_num_bits int32 | f32, num_bits f32 | None), [L, B, C]."""
     means_bc = _dev(means_bc, torch.float32, "means")
     spread_bc = _dev(spread_bc, torch.float32, "spread")
     if means_bc.dim() != 2 or means_bc.shape != spread_bc.shape:
@@ -428,7 +440,7 @@ def compress_latents(means_bc: torch.Tensor, spread_bc: torch.Tensor, table_lm: 
     raw = torch.empty((L, B, Cc), dtype=torch.int32 if level_len is None else torch.float32, device=dev)
     nb = torch.empty((L, B, Cc), dtype=torch.float32, device=dev) if models is not None else None
     if B:
-        check(h.vbq_compress_latents_f32(_ptr(means_bc), _ptr(spread_bc), int(bool(spread_is_variance)), B, Cc, _ptr(table_lm),
+        check(h.vbq_compress_latents_f32(_ptr(means_bc), _ptr(spread_bc), _spread_kind(spread), B, Cc, _ptr(table_lm),
                                          _ptr(table_sorted), _ptr(level_len), _ptr(models), _doubles(lambdas), L, N, _ptr(z),
                                          _ptr(raw), _ptr(nb), _ptr(ws), ws.numel() * ws.element_size(), _stream(means_bc)),
               "vbq_compress_latents_f32")

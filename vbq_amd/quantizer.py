@@ -353,17 +353,18 @@ class ChannelwisePriorCDFQuantizer:
             self._dev_cache[name] = ws
         return ws
 
-    def _latents_call(self, means_bc, spread_bc, lambs, *, spread_is_variance, level_len, models):
+    def _latents_call(self, means_bc, spread_bc, lambs, *, spread, level_len, models):
         """vbq_compress_latents_f32: planes, solve and the fused lookups of one batch in ONE C call (three launches).
         -> (Z_hat, raw_num_bits, num_bits | None), channel-last [L, B, C] device tensors."""
         from . import _lib
         N, C = self.max_bits_per_coord, self.num_channels
         if getattr(self, "validate_inputs", False):
-            ops.check_inputs(means_bc.contiguous(), (torch.sqrt(spread_bc) if spread_is_variance else spread_bc).contiguous())
+            sig = spread_bc if spread == "sigma" else (torch.exp(spread_bc) ** 0.5 if spread == "logvar" else torch.sqrt(spread_bc))
+            ops.check_inputs(means_bc.contiguous(), sig.contiguous())
         B = means_bc.shape[0]
         ws = self._workspace("_ws_latents", _lib.lib().vbq_compress_latents_workspace_bytes(B, C, len(lambs), N))
         return ops.compress_latents(means_bc, spread_bc, self._table_dev(), self._sorted_dev(), [float(l) for l in lambs], N=N,
-                                    spread_is_variance=spread_is_variance, level_len=level_len, models=models, workspace=ws)
+                                    spread=spread, level_len=level_len, models=models, workspace=ws)
 
     def _batch_dev(self, batch_means, batch_stds):
         mu = torch.as_tensor(_to_numpy(batch_means) if not isinstance(batch_means, torch.Tensor) else batch_means)
@@ -380,7 +381,7 @@ class ChannelwisePriorCDFQuantizer:
         float32 (n + overhead) afterwards, as in the reference."""
         lambs = list(lambs)
         mu, sg = self._batch_dev(batch_means, batch_stds)
-        zhat, bits, _ = self._latents_call(mu, sg, lambs, spread_is_variance=False, level_len=self._level_len_dev(lambs), models=None)
+        zhat, bits, _ = self._latents_call(mu, sg, lambs, spread="sigma", level_len=self._level_len_dev(lambs), models=None)
         Z_hat_dict, num_bits_dict = {}, {}
         for i, lamb in enumerate(lambs):
             z, b = zhat[i], bits[i]                                                  # B x C
@@ -497,9 +498,9 @@ class ChannelwisePriorCDFQuantizer:
         return self._keyed_dev("entropy_models", [em[lamb] for lamb in lambs], models_host)
 
     def compress_latents(self, posterior_means, posterior_logvars, lambs, return_np=True):
-        """quantizer.py:190-240.  One torch op (exp) and ONE C call = three launches (vbq_compress_latents_f32: planes with
-        sigma = sqrt(exp(logvar)) folded in, the solve, and one pass over the indices that writes Z_hat, raw_num_bits and
-        num_bits channel-last).  return_np=False keeps the per-lambda results on the device (torch tensors shaped like the
+        """quantizer.py:190-240 as ONE C call = three launches (vbq_compress_latents_f32: planes with the
+        `exp(posterior_logvars) ** 0.5` of :197,202 folded in, the solve, and one pass over the indices that writes Z_hat,
+        raw_num_bits and num_bits channel-last); no torch arithmetic anywhere in it.  return_np=False keeps the per-lambda results on the device (torch tensors shaped like the
         latents): no 150 MB device-to-host copy per Kodak image x 32 lambdas, which is what bounds the NumPy form (PCIe).
         The reference returns NumPy arrays (np.reshape moves to the CPU, :237); that is the default here too."""
         lambs = list(lambs)
@@ -509,8 +510,8 @@ class ChannelwisePriorCDFQuantizer:
         lv = posterior_logvars if isinstance(posterior_logvars, torch.Tensor) else torch.from_numpy(_to_numpy(posterior_logvars))
         m, lv = m.to(self.device, torch.float32), lv.to(self.device, torch.float32)
         assert lv.shape[-1] == C                                                     # quantizer.py:195
-        var = torch.exp(lv)                            # quantizer.py:197; the ** 0.5 of :202 is taken in the planes kernel
-        zhat, raw_bits, num_bits = self._latents_call(m.reshape(-1, C), var.reshape(-1, C), lambs, spread_is_variance=True,
+        # sigma = exp(logvar) ** 0.5 (quantizer.py:197,202) is taken inside the planes kernel
+        zhat, raw_bits, num_bits = self._latents_call(m.reshape(-1, C), lv.reshape(-1, C), lambs, spread="logvar",
                                                       level_len=self._level_len_dev(lambs), models=self._models_dev(lambs))
         out_keys = ("Z_hat", "raw_num_bits", "num_bits_cl", "num_bits")
         output = {key: dict() for key in out_keys}
