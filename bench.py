@@ -436,8 +436,7 @@ def run_workload(name, args, torch, dist, dev, rank, world, steps, warmup, detai
     def step():
         if mu_in is not None:
             timers("layout", 0)
-            ops.transpose(mu_in, out=mu)
-            ops.transpose(sg_in, out=sg)
+            ops.prep_planes(mu_in, sg_in, out_mu=mu, out_sigma=sg)      # both layout changes in one launch
             timers("layout", 1)
         build.run(mu, sg)
 
