@@ -525,7 +525,8 @@ class ChannelwisePriorCDFQuantizer:
             # kept for later does not pin L times its own size of page-locked memory (an evaluation loop over a whole
             # data set would otherwise accumulate GBs of it).
             stage = self._dev_cache.setdefault("_pinned_stage", {})
-            host = {}
+            host, done = {}, {}
+            st = torch.cuda.current_stream(self.device)
             for key, t in (("Z_hat", zhat), ("raw_num_bits", raw_bits), ("num_bits", num_bits)):
                 h = stage.get(key)
                 if h is None or h.numel() < t.numel() or h.dtype != t.dtype:
@@ -533,8 +534,20 @@ class ChannelwisePriorCDFQuantizer:
                     stage[key] = h
                 h[:t.numel()].view(t.shape).copy_(t, non_blocking=True)
                 host[key] = h[:t.numel()].view(t.shape)
-            torch.cuda.current_stream(self.device).synchronize()
-            arrs = {key: np.array(h.numpy().reshape((L,) + shape)) for key, h in host.items()}    # [L, B, C] -> L x latent shape (:237)
+                done[key] = torch.cuda.Event()
+                done[key].record(st)
+
+            def copy_out(key):               # the copy out of the staging block of one quantity overlaps the next one's transfer
+                done[key].synchronize()
+                return np.array(host[key].numpy().reshape((L,) + shape))     # [L, B, C] -> L x latent shape (:237)
+            if zhat.numel() * 4 >= (1 << 22):    # NumPy releases the GIL for large copies: the three run side by side
+                from concurrent.futures import ThreadPoolExecutor
+                pool = self._dev_cache.get("_copy_pool")
+                if pool is None:
+                    pool = self._dev_cache["_copy_pool"] = ThreadPoolExecutor(max_workers=3)
+                arrs = dict(zip(host, pool.map(copy_out, list(host))))
+            else:
+                arrs = {key: copy_out(key) for key in host}
         has_cl = bool(self.raw_code_length_entropy_models)
         for i, lamb in enumerate(lambs):
             output["Z_hat"][lamb] = arrs["Z_hat"][i]
