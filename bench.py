@@ -356,19 +356,33 @@ def launch_ranks(n):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True if r == 0 else None))
-    out0, _ = procs[0].communicate()                          # rank 0 ends after the last collective: the others are done too
-    rcs = [procs[0].returncode]
-    deadline = time.time() + 120
-    for p in procs[1:]:
-        try:
-            rcs.append(p.wait(timeout=max(1.0, deadline - time.time())))
-        except subprocess.TimeoutExpired:
-            p.kill()                                           # this exact child, nothing else
-            rcs.append(p.wait())
+    import threading
+    buf = []
+    reader = threading.Thread(target=lambda: buf.extend(procs[0].stdout), daemon=True)      # drain rank 0's stdout as it comes
+    reader.start()
+    # A rank that dies early (no such device, a failed build) would leave the others waiting in the rendezvous for many
+    # minutes: watch all of them and end the rest -- these exact children, nothing else -- as soon as one has failed.
+    failed = False
+    while any(p.poll() is None for p in procs):
+        if any(p.poll() not in (None, 0) for p in procs):
+            failed = True
+            deadline = time.time() + 5.0                       # let the others fail on their own first (their messages matter)
+            while time.time() < deadline and any(p.poll() is None for p in procs):
+                time.sleep(0.1)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            break
+        time.sleep(0.2)
+    rcs = [p.wait() for p in procs]
+    reader.join(timeout=10)
+    out0 = "".join(buf)
+    if failed:
+        out0 = "\n".join(l for l in out0.splitlines() if not l.startswith("{"))      # no record from a failed job
     lines = [l for l in (out0 or "").splitlines() if l.strip()]
-    for l in lines[:-1]:
+    for l in (lines if failed else lines[:-1]):
         print(l, file=sys.stderr)
-    if lines:
+    if lines and not failed:
         print(lines[-1], flush=True)
     bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
     if bad:
@@ -740,6 +754,8 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world and rank == 0:
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: running the {world} ranks that were launched", file=sys.stderr)
+    if os.environ.get("VBQ_BENCH_TEST_STALL_RANK") == str(rank):      # testing switch: a rank stuck where a rendezvous would leave it
+        time.sleep(600)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm device")
     # VBQ_BENCH_ONE_DEVICE=1 (+ VBQ_BENCH_BACKEND=gloo) lets the N > 1 code path be exercised on a

@@ -282,3 +282,18 @@ def test_device_models_is_a_lazy_dict():
     q.entropy_models = DeviceModels(lambs, stack)
     q2 = pickle.loads(pickle.dumps(q))
     assert type(q2.entropy_models) is dict and np.array_equal(q2.entropy_models[0.5], stack[0].numpy())
+
+
+@pytest.mark.timeout(300)
+def test_bench_self_launch_ends_the_ranks_left_behind_by_a_failed_one():
+    """One rank dies at once, the other is stuck (as it would be in the rendezvous, waiting for the dead one): the launcher
+    must notice the failure, end the stuck child and exit non-zero within seconds, not after the rendezvous timeout."""
+    import subprocess
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", VBQ_BENCH_TEST_STALL_RANK="0")
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=280, cwd=ROOT)
+    assert r.returncode != 0 and time.time() - t0 < 120
+    assert "ranks failed" in r.stderr and not r.stdout.strip()
