@@ -157,9 +157,10 @@ class EntropyModelBuild:
             return t
         self.idx = kept(("idx", L, C, self.rows, str(self.dev)),
                         lambda: torch.empty((L, C, self.rows), dtype=torch.uint16, device=self.dev))
-        self.level_counts = torch.zeros((L, C, N1), dtype=torch.int64, device=self.dev)
+        self.level_counts = torch.empty((L, C, N1), dtype=torch.int64, device=self.dev)      # zeroed at the head of every pass 1
         # two rank-histogram buffers when sharded: step i's all-reduce runs while step i+1 fills the other one
-        self._counts2 = [torch.zeros((L, C, T), dtype=counts_dtype, device=self.dev) for _ in range(2 if self.world > 1 else 1)]
+        # (pass 2 assigns every bin, or zeroes the buffer itself before it accumulates: no fill here -- 67 MB at C = 256)
+        self._counts2 = [torch.empty((L, C, T), dtype=counts_dtype, device=self.dev) for _ in range(2 if self.world > 1 else 1)]
         self._slot = 0
         self.counts = self._counts2[0]
         self.ws = kept(("ws", L, C, N, str(self.dev)),
