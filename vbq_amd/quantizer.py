@@ -67,6 +67,7 @@ class DeviceModels(MutableMapping):
         self._host = None
         self._over = {}                      # entries the caller replaced or added
         self._gone = set()
+        self._subsets = {}                   # device rows of key subsets already gathered (an evaluation loop asks again and again)
 
     @property
     def on_device(self) -> bool:
@@ -93,8 +94,10 @@ class DeviceModels(MutableMapping):
     def __setitem__(self, k, v):
         self._over[k] = v
         self._gone.discard(k)
+        self._subsets.clear()
 
     def __delitem__(self, k):
+        self._subsets.clear()
         if k in self._over:
             del self._over[k]
             if k in self._index:
@@ -130,7 +133,13 @@ class DeviceModels(MutableMapping):
         t = self._stack if companion is None else self._companions[companion]
         if keys == self._keys:
             return t
-        return t[[self._index[k] for k in keys]].contiguous()
+        which = (companion, tuple(self._index[k] for k in keys))
+        sub = self._subsets.get(which)
+        if sub is None:
+            if len(self._subsets) > 8:
+                self._subsets.clear()
+            sub = self._subsets[which] = t[list(which[1])].contiguous()
+        return sub
 
     def to_dict(self):
         return {k: self[k] for k in self}
