@@ -332,6 +332,20 @@ def test_api_fuzz_small(ops):
     assert bad == 0 and solves > 1e6
 
 
+def test_latents_call_fuzz_small(ops):
+    """A short run of the second half of tools/fuzz_api.py: the per-image call (vbq_compress_latents_f32: every spread kind,
+    vector and scalar tiles of the planes / lookup kernels, raw and corrected lengths, with and without entropy models) and the
+    facade's output forms against the oracle on random shapes."""
+    from tools import fuzz_api
+    rng = np.random.default_rng(321)
+    solves = 0
+    for case in range(60):
+        desc, n = fuzz_api.one_latents_case(rng, torch.device("cuda"))
+        assert desc is None, f"case {case}: {desc}"
+        solves += n
+    assert solves > 1e6
+
+
 @pytest.mark.parametrize("Nbits", [11, 12])
 def test_bit_depths_above_ten_on_planes(ops, Nbits):
     """N = 11, 12 (4095 / 8191 code points): K1 and K2 on channel-major planes and on one code book, raw and

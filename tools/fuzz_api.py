@@ -103,6 +103,57 @@ def one_case(rng, dev):
     return (desc if miss else None), rows * C * L
 
 
+def one_latents_case(rng, dev):
+    """vbq_compress_latents_f32 (planes + solve + fused lookups in one call), vbq_gather_latents_u16 on its own and the facade's
+    output forms against the oracle: random C (vector and scalar tiles), ragged rows, every spread kind, raw / corrected lengths."""
+    import vbq_amd
+    N = int(rng.choice([10, 10, 10, 8, 11, 5]))
+    T = 2 ** (N + 1) - 1
+    C = int(rng.choice([1, 2, 3, 4, 7, 8, 20, 64, 68, 70, 130]))
+    rows = int(rng.choice([1, 3, 8, 31, 32, 33, 64, 200, 513, 1536]))
+    L = int(rng.choice([1, 2, 3, 5, 16, 20, 32]))
+    xi = np.concatenate([(np.arange(2 ** n) + 0.5) / 2 ** n for n in range(N + 1)])
+    scale = np.exp(rng.uniform(np.log(0.1), np.log(10), C))
+    tab = norm.ppf(xi[None, :], scale=scale[:, None]).astype(np.float32)
+    srt = np.sort(tab, axis=1)
+    mu = (scale * rng.standard_t(4, (rows, C))).astype(np.float32)
+    lv = rng.normal(-4, 2.0, (rows, C)).astype(np.float32) + 2 * np.log(scale).astype(np.float32)
+    lam = [float(v) for v in np.exp(rng.uniform(np.log(1e-3), np.log(300), L))]
+    kind = str(rng.choice(["sigma", "variance", "logvar"]))
+    lv_d = torch.from_numpy(lv).to(dev)
+    sig_d = torch.exp(lv_d) ** 0.5                                   # what every kind must amount to
+    spread = {"sigma": sig_d, "variance": torch.exp(lv_d), "logvar": lv_d}[kind]
+    if kind == "variance":
+        sig_d = torch.sqrt(spread)
+    sg = sig_d.cpu().numpy()
+    ll = models = None
+    if rng.random() < 0.6:
+        ll = (np.arange(N + 1, dtype=np.float32)[None, None, :] + np.abs(rng.normal(0, 1.5, (L, C, N + 1)))).astype(np.float32)
+    if rng.random() < 0.7:
+        models = rng.uniform(0.2, 16, (L, C, T)).astype(np.float32)
+    wi, wz, wb = CO.quantize(mu, sg, tab, lam, N=N, level_len=ll, want_zhat=True, want_bits=True, threads=8)
+    d = lambda a: None if a is None else torch.from_numpy(a).to(dev)
+    z, raw, nb = ops.compress_latents(d(mu), spread, d(tab), d(srt), lam, N=N, spread=kind, level_len=d(ll), models=d(models))
+    miss = int((z.cpu().numpy() != wz).sum()) + int((raw.cpu().numpy() != (wb if ll is not None else wb.astype(np.int32))).sum())
+    if models is not None:
+        want_nb = models[np.arange(L)[:, None, None], np.arange(C)[None, None, :], wi.astype(np.int64)]
+        miss += int((nb.cpu().numpy() != want_nb).sum())
+    # the facade on the same latents: channel-last and planes out, values / lengths / no indices
+    if N <= 10 or C == 1:
+        form = int(rng.integers(0, 3))
+        if form == 0:
+            got = vbq_amd.quantize(d(mu), sig_d, lam, table=tab, N=N, lengths=ll, return_values=True, return_bits=True)
+            miss += sum(int((g.cpu().numpy() != w).sum()) for g, w in zip(got, (wi, wz, wb)))
+        elif form == 1:
+            got = vbq_amd.quantize(d(mu), sig_d, lam, table=tab, N=N, lengths=ll, out_layout="planes", return_values=True)
+            miss += sum(int((g.cpu().numpy().reshape(L, C, rows).transpose(0, 2, 1) != w).sum()) for g, w in zip(got, (wi, wz)))
+        else:
+            got = vbq_amd.quantize(d(mu), sig_d, lam, table=tab, N=N, lengths=ll, return_values=True, return_indices=False)
+            miss += int((got.cpu().numpy() != wz).sum())
+    desc = f"latents N={N} C={C} rows={rows} L={L} spread={kind} ll={ll is not None} models={models is not None}: {miss} mismatches"
+    return (desc if miss else None), rows * C * L
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=300)
@@ -110,4 +161,13 @@ if __name__ == "__main__":
     a = ap.parse_args()
     bad, solves = run(a.cases, a.seed)
     print(f"{a.cases} cases, {solves:.3g} solves, {bad} failing cases")
-    sys.exit(1 if bad else 0)
+    rng2 = np.random.default_rng(a.seed + 10_000)
+    bad2 = solves2 = 0
+    for case in range(a.cases):
+        desc, n = one_latents_case(rng2, torch.device("cuda"))
+        solves2 += n
+        if desc:
+            bad2 += 1
+            print(f"case {case}: {desc}")
+    print(f"{a.cases} per-image-call / facade cases, {solves2:.3g} solves, {bad2} failing cases")
+    sys.exit(1 if bad or bad2 else 0)
