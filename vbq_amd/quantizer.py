@@ -297,12 +297,13 @@ class ChannelwisePriorCDFQuantizer:
         return left, right
 
     # ------------------------------------------------------------------ the solve
-    def _prep(self, batch_means, batch_stds):
-        mu, sg = self._batch_dev(batch_means, batch_stds)
+    def _prep(self, batch_means, batch_spread, spread="sigma"):
+        """Channel-major planes [C, B] of the means and the standard deviations, both in one launch; `spread` says what
+        batch_spread holds ('sigma', or 'logvar': sigma = exp(.) ** 0.5 is taken on the way, quantizer.py:87,92)."""
+        mu, sp = self._batch_dev(batch_means, batch_spread)
         if getattr(self, "validate_inputs", False):
-            ops.check_inputs(mu.contiguous(), sg.contiguous())
-        # channel-major planes [C, B], both in one launch
-        return ops.prep_planes(mu, sg)
+            ops.check_inputs(mu.contiguous(), (sp if spread == "sigma" else torch.exp(sp) ** 0.5).contiguous())
+        return ops.prep_planes(mu, sp, spread=spread)
 
     def _keyed_dev(self, name: str, arrays, builder):
         """Device copy of a table assembled from per-lambda model arrays, rebuilt only when one of those arrays is
@@ -350,9 +351,6 @@ class ChannelwisePriorCDFQuantizer:
         """u16 rank indices [L, C, B] on the device."""
         return ops.quantize(mu_cb, sg_cb, self._table_dev(), [float(l) for l in lambs], N=self.max_bits_per_coord,
                             level_len=level_len, layout="cb")
-
-    def _rank_levels_dev(self):
-        return self._dev("rank_levels", lambda: torch.from_numpy(_entropy.rank_levels(self.max_bits_per_coord)))
 
     def _workspace(self, name: str, nbytes: int) -> torch.Tensor:
         """A persistent device workspace, grown on demand (planes + index planes of the per-image call)."""
@@ -405,18 +403,15 @@ class ChannelwisePriorCDFQuantizer:
         lv = posterior_logvars if isinstance(posterior_logvars, torch.Tensor) else torch.from_numpy(_to_numpy(posterior_logvars))
         return m.to(self.device, torch.float32), lv.to(self.device, torch.float32)
 
-    def _flatten(self, means, logvars):
-        C = logvars.shape[-1]
-        assert C == self.num_channels                                               # quantizer.py:89,195
-        batch_means = means.reshape(-1, C)
-        batch_stds = torch.exp(logvars).reshape(-1, C) ** 0.5                        # quantizer.py:87,92
-        return batch_means, batch_stds
-
     def build_entropy_models(self, X, vae, lambs, add_n_smoothing):
         means, logvars = self._encode(X, vae)
-        return self.build_entropy_models_from_latents(*self._flatten(means, logvars), lambs, add_n_smoothing)
+        C = logvars.shape[-1]
+        assert C == self.num_channels                                               # quantizer.py:89
+        # batch_stds = exp(posterior_logvars) ** 0.5 (quantizer.py:87,92) is taken inside the planes kernel
+        return self.build_entropy_models_from_latents(means.reshape(-1, C), logvars.reshape(-1, C), lambs, add_n_smoothing,
+                                                      spread="logvar")
 
-    def build_entropy_models_from_latents(self, batch_means, batch_stds, lambs, add_n_smoothing):
+    def build_entropy_models_from_latents(self, batch_means, batch_stds, lambs, add_n_smoothing, spread="sigma"):
         """The body of quantizer.py:94-150 on (B x C) means/stds: vbq_amd.pipeline.EntropyModelBuild (pass 1 = solve +
         bit-length histogram in one kernel, length table on the device, pass 2 = solve + rank histogram + models).
         NOTHING here waits for the device: the three tables stay where the kernels wrote them behind dict-like views
@@ -427,7 +422,7 @@ class ChannelwisePriorCDFQuantizer:
         from .pipeline import EntropyModelBuild
         lambs = list(lambs)
         N, C = self.max_bits_per_coord, self.num_channels
-        mu_cb, sg_cb = self._prep(batch_means, batch_stds)
+        mu_cb, sg_cb = self._prep(batch_means, batch_stds, spread)
         B = mu_cb.shape[1]
         B_global, distributed = B, self.process_group is not None
         if distributed:
