@@ -221,10 +221,176 @@ k_gather_latents_vec(const uint16_t *__restrict__ idx, long B, int C, const floa
     (void)live;
 }
 
+// ---------------------------------------------------------------------------- lookups out of LDS-resident tables
+// k_gather_latents reads its tables through L2, and every lane of a lookup hits its own 64-byte sector: 3.2e11 lookups/s
+// chip-wide whatever the tile shape (EXPERIMENTS.md).  For LARGE batches the tables can live in the LDS instead: one workgroup
+// of 1024 threads owns 16 channels -- 16 tables of 8 KB = 128 KB of the CU's 160 KB -- wave w serves channel c0 + w, a lane
+// reads four consecutive indices of its channel (8 bytes), looks them up in the LDS and parks the four values as one 16-byte
+// LDS write in a [16 channels][256 rows] tile; after a barrier every thread takes four channels of one row out of the tile and
+// stores 16 bytes: the output rows leave as 64-byte segments (16 channels x f32).  Two kinds of pass:
+//   per_lambda == 0   tab = d_table_sorted [C][T]: the tables do not depend on lambda -- a workgroup keeps them for ALL lambdas
+//                     of its row range (blockIdx.y splits the rows); outputs Z_hat, optionally raw_num_bits
+//   per_lambda == 1   tab = d_models [L][C][T]: a workgroup owns ONE lambda (blockIdx.y) and all rows; output num_bits
+// Worth it when a staged table entry is looked up many times (the launcher's rule); N <= 10, B % 4 == 0, C % 4 == 0.
+// Two tiles of [16][256] floats, used in turn (one barrier per emitted output instead of two); no padding fits beside the tables,
+// so the rows of channels 4..7 and 12..15 are stored with bit 4 flipped: the row-wise reads of the four channel groups then fall
+// on banks 0-15 / 16-31 / 0-15 / 16-31 (2-way, the minimum for 64 lanes) and the 16-byte writes stay whole.
+constexpr int kLdsCh = 16, kLdsRows = 256, kLdsPitch = kLdsRows;
+// From where the LDS form is taken (measured, C = 256, tools/gather_bench.py: one image of 1 536 rows x 16 lambdas -- num_bits 22.8
+// against 32.8 us, Z_hat + lengths 36 against 30; two images -- both faster: 74.6 against 107 us for all three outputs):
+constexpr int64_t kLdsMinLookupsZ = 1 << 15;         // lambdas x rows per channel table (Z_hat, with raw_num_bits riding along)
+constexpr int64_t kLdsMinLookupsNb = 1 << 10;        // rows per (lambda, channel) table (num_bits)
+template <int N>
+__global__ void __launch_bounds__(1024)
+k_lookup_lds(const uint16_t *__restrict__ idx, long B, int C, int L, const float *__restrict__ tab, int per_lambda,
+             const float *__restrict__ level_len, float *__restrict__ out_a, float *__restrict__ out_raw, int raw_as_int,
+             long rows_per_split) {
+    constexpr int T = table_size(N), TP = T, N1 = N + 1;
+    extern __shared__ float lds_f[];
+    float *tabs = lds_f;                                       // [16][T]
+    float *tiles = lds_f + ((kLdsCh * TP + 3) & ~3);           // two tiles [16][256], 16-byte aligned
+    int flip = 0;
+    // Workgroups go to the 8 XCDs round-robin by their linear number.  A workgroup writes 64-byte halves of 128-byte lines; with
+    // the channel groups renumbered inside every block of 16 so that groups 2k and 2k + 1 get numbers 8 apart, the two halves of a
+    // line are written by workgroups of ONE XCD, walking the same rows in the same order, and meet in that XCD's L2.
+    int grp = blockIdx.x;
+    if ((gridDim.x & 15) == 0) grp = (grp & ~15) + ((grp & 7) << 1) + ((grp >> 3) & 1);
+    const int c0 = grp * kLdsCh;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c = c0 + w;
+    const bool ch_ok = c < C;
+    const int l_begin = per_lambda ? (int)blockIdx.y : 0, l_end = per_lambda ? (int)blockIdx.y + 1 : L;
+    const long r_begin = per_lambda ? 0 : (long)blockIdx.y * rows_per_split;
+    const long r_end = per_lambda ? B : (r_begin + rows_per_split < B ? r_begin + rows_per_split : B);
+    const long E = B * (long)C;
+    for (int l = l_begin; l < l_end; ++l) {
+        if (per_lambda || l == l_begin) {                       // stage the 16 tables (coalesced rows of 8 KB)
+            if (per_lambda && l != l_begin) __syncthreads();    // (a workgroup owns one lambda in that mode: never taken today)
+            for (int i = threadIdx.x; i < kLdsCh * TP; i += blockDim.x) {
+                const int tc = i / TP, e = i - tc * TP;
+                const int cc = c0 + tc < C ? c0 + tc : C - 1;
+                tabs[i] = tab[((per_lambda ? (long)l * C : 0) + cc) * T + e];
+            }
+            __syncthreads();
+        }
+        float llv[N1];                                          // this wave's channel: code length of every bit level
+        if (out_raw && level_len) {
+#pragma unroll
+            for (int n = 0; n < N1; ++n) llv[n] = level_len[((long)l * C + (ch_ok ? c : C - 1)) * N1 + n];
+        }
+        const uint16_t *src = idx + ((long)l * C + (ch_ok ? c : 0)) * B;
+        auto load4 = [&](long r0) {                             // B % 4 == 0: four indices are inside or outside together
+            const long r = r0 + 4 * lane;
+            return (ch_ok && r < r_end) ? *reinterpret_cast<const uint2 *>(src + r) : make_uint2(0, 0);
+        };
+        uint2 q2n = load4(r_begin);
+        for (long r0 = r_begin; r0 < r_end; r0 += kLdsRows) {
+            const uint2 q2 = q2n;
+            q2n = load4(r0 + kLdsRows);                         // the next block's indices travel while this one is looked up
+            const int q[4] = {(int)(q2.x & 0xffffu), (int)(q2.x >> 16), (int)(q2.y & 0xffffu), (int)(q2.y >> 16)};
+            float v[4], rw[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int qq = min(q[j], T - 1);
+                v[j] = tabs[w * TP + qq];
+                if (out_raw) {
+                    const int lvl = N - __builtin_ctz((unsigned)qq + 1u);
+                    float x = raw_as_int ? __int_as_float(lvl) : (float)lvl;
+                    if (level_len) {
+                        x = llv[0];
+#pragma unroll
+                        for (int n = 1; n < N1; ++n) x = lvl == n ? llv[n] : x;
+                    }
+                    rw[j] = x;
+                }
+            }
+            auto emit = [&](const float (&val)[4], float *__restrict__ out) {
+                float *tile = tiles + flip * (kLdsCh * kLdsPitch);
+                flip ^= 1;                                      // the tile written two emits ago is free again: a barrier lies between
+                *reinterpret_cast<float4 *>(tile + w * kLdsPitch + ((4 * lane) ^ ((w & 4) << 2))) = make_float4(val[0], val[1], val[2], val[3]);
+                __syncthreads();
+                const int row = threadIdx.x >> 2, g = threadIdx.x & 3, ch4 = g * 4;
+                const int rs = row ^ ((g & 1) << 4);            // (ch4 & 4) << 2: the flip of this channel group's rows
+                const long rr = r0 + row;
+                if (rr < r_end && c0 + ch4 < C)                  // C % 4 == 0: four channels are inside or outside together
+                    *reinterpret_cast<float4 *>(out + (long)l * E + rr * C + c0 + ch4) =
+                        make_float4(tile[ch4 * kLdsPitch + rs], tile[(ch4 + 1) * kLdsPitch + rs], tile[(ch4 + 2) * kLdsPitch + rs],
+                                    tile[(ch4 + 3) * kLdsPitch + rs]);
+            };
+            emit(v, out_a);
+            if (out_raw) emit(rw, out_raw);
+        }
+    }
+}
+
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+// LDS passes (k_lookup_lds) for the outputs they pay for; returns through *did_z / *did_nb which outputs they produced.
+template <int N>
+int lookup_lds_passes(const uint16_t *idx, int64_t B, int32_t C, int32_t L, const float *tab_sorted, const float *level_len,
+                      const float *models, float *out_z, void *out_raw, float *out_nb, bool *did_z, bool *did_nb, hipStream_t st) {
+    *did_z = *did_nb = false;
+    if constexpr (N > 10) {
+        return VBQ_OK;
+    } else {
+        static const int mode = [] { const char *e = getenv("VBQ_LOOKUP_LDS"); return e ? atoi(e) : -1; }();   // A/B: 0 never, 1 always
+        const uintptr_t al = reinterpret_cast<uintptr_t>(out_z) | reinterpret_cast<uintptr_t>(out_raw) | reinterpret_cast<uintptr_t>(out_nb);
+        if (mode == 0 || B % 4 != 0 || C % 4 != 0 || (al & 15) != 0 || (reinterpret_cast<uintptr_t>(idx) & 7) != 0) return VBQ_OK;
+        constexpr int TP = table_size(N);
+        const size_t lds = sizeof(float) * (size_t)(((kLdsCh * TP + 3) & ~3) + 2 * kLdsCh * kLdsPitch);
+        const int groups = (C + kLdsCh - 1) / kLdsCh;
+        // a staged table entry must be looked up often enough to pay for its staging: measured break-even (tools/gather_bench.py)
+        const bool want_z = out_z != nullptr && (mode == 1 || mode == 3 || (mode < 0 && (int64_t)L * B >= kLdsMinLookupsZ));
+        const bool want_nb = out_nb != nullptr && (mode == 1 || mode == 2 || (mode < 0 && B >= kLdsMinLookupsNb));
+        if (!want_z && !want_nb) return VBQ_OK;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lookup_lds<N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            set_error("hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
+            return VBQ_ERR_LAUNCH;
+        }
+        if (want_z) {
+            int64_t splits = (2 * (int64_t)num_cus() + groups - 1) / groups;                 // about two workgroups per CU in all
+            const int64_t blocks = (B + kLdsRows - 1) / kLdsRows;
+            if (splits > blocks) splits = blocks;
+            if (splits < 1) splits = 1;
+            const int64_t per = ((blocks + splits - 1) / splits) * kLdsRows;
+            splits = (B + per - 1) / per;
+            VBQ_REQUIRE(splits <= 65535, VBQ_ERR_UNSUPPORTED, "vbq_gather_latents_u16: grid too large");
+            hipLaunchKernelGGL((k_lookup_lds<N>), dim3((unsigned)groups, (unsigned)splits), dim3(1024), lds, st, idx, (long)B, (int)C, (int)L,
+                               tab_sorted, 0, level_len, out_z, static_cast<float *>(out_raw), (int)(level_len == nullptr), (long)per);
+            VBQ_CHECK_LAUNCH("lookup_lds (sorted table)");
+            *did_z = true;
+        }
+        if (want_nb) {
+            VBQ_REQUIRE(L <= 65535, VBQ_ERR_UNSUPPORTED, "vbq_gather_latents_u16: grid too large");
+            hipLaunchKernelGGL((k_lookup_lds<N>), dim3((unsigned)groups, (unsigned)L), dim3(1024), lds, st, idx, (long)B, (int)C, (int)L,
+                               models, 1, nullptr, out_nb, static_cast<float *>(nullptr), 0, (long)B);
+            VBQ_CHECK_LAUNCH("lookup_lds (entropy models)");
+            *did_nb = true;
+        }
+        return VBQ_OK;
+    }
+}
 
 int gather_latents(const uint16_t *idx, int64_t B, int32_t C, int32_t L, int32_t N, const float *tab_sorted, const float *level_len,
                    const float *models, float *out_z, void *out_raw, float *out_nb, uint16_t *out_idx, hipStream_t st) {
+    {   // large batches: tables in the LDS for the outputs that pay for it, the generic kernel for what is left
+        bool did_z = false, did_nb = false;
+        int rc = VBQ_OK;
+#define VBQ_DISPATCH_N(NN)                                                                                              \
+    case NN:                                                                                                            \
+        rc = lookup_lds_passes<NN>(idx, B, C, L, tab_sorted, level_len, models, out_z, out_raw, out_nb, &did_z, &did_nb, st); \
+        break;
+        switch (N) {
+            VBQ_FOR_EACH_N(VBQ_DISPATCH_N)
+            default: break;
+        }
+#undef VBQ_DISPATCH_N
+        if (rc != VBQ_OK) return rc;
+        if (did_z) { out_z = nullptr; out_raw = nullptr; }
+        if (did_nb) out_nb = nullptr;
+        if (!out_z && !out_raw && !out_nb && !out_idx) return VBQ_OK;
+    }
     const uintptr_t all = reinterpret_cast<uintptr_t>(idx) | reinterpret_cast<uintptr_t>(out_z) | reinterpret_cast<uintptr_t>(out_raw) |
                           reinterpret_cast<uintptr_t>(out_nb) | reinterpret_cast<uintptr_t>(out_idx);
     static const bool scalar_only = [] { const char *e = getenv("VBQ_GATHER_SCALAR"); return e && e[0] == '1'; }();   // A/B timing
