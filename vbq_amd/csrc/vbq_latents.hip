@@ -236,10 +236,13 @@ k_gather_latents_vec(const uint16_t *__restrict__ idx, long B, int C, const floa
 // so the rows of channels 4..7 and 12..15 are stored with bit 4 flipped: the row-wise reads of the four channel groups then fall
 // on banks 0-15 / 16-31 / 0-15 / 16-31 (2-way, the minimum for 64 lanes) and the 16-byte writes stay whole.
 constexpr int kLdsCh = 16, kLdsRows = 256, kLdsPitch = kLdsRows;
-// From where the LDS form is taken (measured, C = 256, tools/gather_bench.py: one image of 1 536 rows x 16 lambdas -- num_bits 22.8
-// against 32.8 us, Z_hat + lengths 36 against 30; two images -- both faster: 74.6 against 107 us for all three outputs):
-constexpr int64_t kLdsMinLookupsZ = 1 << 15;         // lambdas x rows per channel table (Z_hat, with raw_num_bits riding along)
-constexpr int64_t kLdsMinLookupsNb = 1 << 10;        // rows per (lambda, channel) table (num_bits)
+// From where the LDS form is taken (C = 256, tools/gather_bench.py and the bench's per-image call).  With uniform random indices it
+// wins from one image on (1 536 rows x 16 lambdas: num_bits 22.8 against 32.8 us); with the indices of a real solve -- a few hot
+// code points per lambda, whose sectors the L2 form's lanes share -- one image is faster in ONE launch of the L2 form (47.7
+// against 51.0 us for the three outputs), two images and more in the LDS form (74.6 against 107 us; Kodak-24 x 32 Z_hat, real
+// indices, inside the facade: 1.23 -> 0.84 ms).
+constexpr int64_t kLdsMinLookupsZ = 3 << 14;         // lambdas x rows per channel table (Z_hat, with raw_num_bits riding along)
+constexpr int64_t kLdsMinLookupsNb = 3 << 10;        // rows per (lambda, channel) table (num_bits)
 template <int N>
 __global__ void __launch_bounds__(1024)
 k_lookup_lds(const uint16_t *__restrict__ idx, long B, int C, int L, const float *__restrict__ tab, int per_lambda,
