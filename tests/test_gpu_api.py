@@ -677,7 +677,10 @@ def test_logvar_to_sigma_is_torchs_for_every_float32():
 
 
 @pytest.mark.parametrize("L,C,B,with_len", [(3, 70, 77, False), (2, 1, 1000, True), (5, 64, 32, True), (1, 130, 33, False),
-                                             (3, 128, 136, False), (2, 68, 200, True), (16, 256, 1536, True)])
+                                             (3, 128, 136, False), (2, 68, 200, True), (16, 256, 1536, True),
+                                             # large enough for the LDS-table form (k_lookup_lds): whole and ragged channel groups,
+                                             # row counts that are not a multiple of its 256-row blocks
+                                             (16, 64, 4096, True), (3, 20, 16388, False), (2, 36, 3076, True)])
 def test_gather_latents_one_pass_against_numpy(L, C, B, with_len):
     """vbq_gather_latents_u16: Z_hat, raw_num_bits, num_bits and the indices themselves, channel-last, from index planes in
     one pass -- against NumPy fancy indexing; ragged tiles, foreign indices >= T clamped like vbq_gather_f32."""

@@ -110,8 +110,10 @@ def one_latents_case(rng, dev):
     N = int(rng.choice([10, 10, 10, 8, 11, 5]))
     T = 2 ** (N + 1) - 1
     C = int(rng.choice([1, 2, 3, 4, 7, 8, 20, 64, 68, 70, 130]))
-    rows = int(rng.choice([1, 3, 8, 31, 32, 33, 64, 200, 513, 1536]))
+    rows = int(rng.choice([1, 3, 8, 31, 32, 33, 64, 200, 513, 1536, 3076, 4096]))     # the last two: the LDS-table lookups
     L = int(rng.choice([1, 2, 3, 5, 16, 20, 32]))
+    if rows > 2000 and C > 20:
+        C = int(rng.choice([4, 8, 20]))                              # keep the oracle's share of a case small
     xi = np.concatenate([(np.arange(2 ** n) + 0.5) / 2 ** n for n in range(N + 1)])
     scale = np.exp(rng.uniform(np.log(0.1), np.log(10), C))
     tab = norm.ppf(xi[None, :], scale=scale[:, None]).astype(np.float32)
