@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from vbq_amd import build as B  # noqa: E402
 
-VARIANT_SOURCES = ["vbq_quantize_fast.hip", "vbq_notebook.hip", "vbq_hist.hip"]
+VARIANT_SOURCES = ["vbq_quantize_fast.hip", "vbq_notebook.hip", "vbq_hist.hip", "vbq_latents.hip"]
 
 
 def one(tag, flags):

@@ -17,6 +17,8 @@
 // built or read.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "vbq_common.h"
 
 namespace vbq {
@@ -235,7 +237,10 @@ k_gather_latents_vec(const uint16_t *__restrict__ idx, long B, int C, const floa
 // Two tiles of [16][256] floats, used in turn (one barrier per emitted output instead of two); no padding fits beside the tables,
 // so the rows of channels 4..7 and 12..15 are stored with bit 4 flipped: the row-wise reads of the four channel groups then fall
 // on banks 0-15 / 16-31 / 0-15 / 16-31 (2-way, the minimum for 64 lanes) and the 16-byte writes stay whole.
-constexpr int kLdsCh = 16, kLdsRows = 256, kLdsPitch = kLdsRows;
+#ifndef VBQ_LDS_AHEAD
+#define VBQ_LDS_AHEAD 2
+#endif
+constexpr int kLdsCh = 16, kLdsRows = 256, kLdsPitch = kLdsRows, kLdsAhead = VBQ_LDS_AHEAD;
 // From where the LDS form is taken (C = 256, tools/gather_bench.py and the bench's per-image call).  With uniform random indices it
 // wins from one image on (1 536 rows x 16 lambdas: num_bits 22.8 against 32.8 us); with the indices of a real solve -- a few hot
 // code points per lambda, whose sectors the L2 form's lanes share -- one image is faster in ONE launch of the L2 form (47.7
@@ -246,9 +251,8 @@ constexpr int64_t kLdsMinLookupsNb = 3 << 10;        // rows per (lambda, channe
 template <int N>
 __global__ void __launch_bounds__(1024)
 k_lookup_lds(const uint16_t *__restrict__ idx, long B, int C, int L, const float *__restrict__ tab, int per_lambda,
-             const float *__restrict__ level_len, float *__restrict__ out_a, float *__restrict__ out_raw, int raw_as_int,
-             long rows_per_split) {
-    constexpr int T = table_size(N), TP = T, N1 = N + 1;
+             float *__restrict__ out_a, long rows_per_split) {
+    constexpr int T = table_size(N), TP = T;
     extern __shared__ float lds_f[];
     float *tabs = lds_f;                                       // [16][T]
     float *tiles = lds_f + ((kLdsCh * TP + 3) & ~3);           // two tiles [16][256], 16-byte aligned
@@ -276,53 +280,56 @@ k_lookup_lds(const uint16_t *__restrict__ idx, long B, int C, int L, const float
             }
             __syncthreads();
         }
-        float llv[N1];                                          // this wave's channel: code length of every bit level
-        if (out_raw && level_len) {
-#pragma unroll
-            for (int n = 0; n < N1; ++n) llv[n] = level_len[((long)l * C + (ch_ok ? c : C - 1)) * N1 + n];
-        }
         const uint16_t *src = idx + ((long)l * C + (ch_ok ? c : 0)) * B;
-        auto load4 = [&](long r0) {                             // B % 4 == 0: four indices are inside or outside together
-            const long r = r0 + 4 * lane;
-            return (ch_ok && r < r_end) ? *reinterpret_cast<const uint2 *>(src + r) : make_uint2(0, 0);
+        // B % 4 == 0: four indices are inside or outside together.  The load is UNCONDITIONAL (rows beyond the range re-read the
+        // channel's last four indices; their results are never stored): a branch around it makes the compiler wait for every
+        // outstanding store before every block (s_waitcnt vmcnt(0) at the loop head) -- stores and lookups then take turns.
+        auto load4 = [&](long r0) {
+            long r = r0 + 4 * lane;
+            r = r < B - 4 ? r : B - 4;
+            return *reinterpret_cast<const uint2 *>(src + r);
         };
-        uint2 q2n = load4(r_begin);
-        for (long r0 = r_begin; r0 < r_end; r0 += kLdsRows) {
-            const uint2 q2 = q2n;
-            q2n = load4(r0 + kLdsRows);                         // the next block's indices travel while this one is looked up
+        // One block of 256 rows: four lookups per lane, the values crossed to row order through an LDS tile, 16-byte stores.
+        // FULL: every row and every channel of the block exists -- the stores are unconditional (no branch in the block).
+        auto block = [&](long r0, uint2 q2, auto full_tag) {
+            constexpr bool FULL = decltype(full_tag)::value;
             const int q[4] = {(int)(q2.x & 0xffffu), (int)(q2.x >> 16), (int)(q2.y & 0xffffu), (int)(q2.y >> 16)};
-            float v[4], rw[4];
+            float v[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int qq = min(q[j], T - 1);
-                v[j] = tabs[w * TP + qq];
-                if (out_raw) {
-                    const int lvl = N - __builtin_ctz((unsigned)qq + 1u);
-                    float x = raw_as_int ? __int_as_float(lvl) : (float)lvl;
-                    if (level_len) {
-                        x = llv[0];
+            for (int j = 0; j < 4; ++j) v[j] = tabs[w * TP + min(q[j], T - 1)];
+            float *tile = tiles + flip * (kLdsCh * kLdsPitch);
+            flip ^= 1;                                          // the tile written two blocks ago is free again: a barrier lies between
+            *reinterpret_cast<float4 *>(tile + w * kLdsPitch + ((4 * lane) ^ ((w & 4) << 2))) = make_float4(v[0], v[1], v[2], v[3]);
+            __syncthreads();
+            const int row = threadIdx.x >> 2, g = threadIdx.x & 3, ch4 = g * 4;
+            const int rs = row ^ ((g & 1) << 4);                // (ch4 & 4) << 2: the flip of this channel group's rows
+            const long rr = r0 + row;
+            if (FULL || (rr < r_end && c0 + ch4 < C))            // C % 4 == 0: four channels are inside or outside together
+                *reinterpret_cast<float4 *>(out_a + (long)l * E + rr * C + c0 + ch4) =
+                    make_float4(tile[ch4 * kLdsPitch + rs], tile[(ch4 + 1) * kLdsPitch + rs], tile[(ch4 + 2) * kLdsPitch + rs],
+                                tile[(ch4 + 3) * kLdsPitch + rs]);
+        };
+        long r0 = r_begin;
+        if (c0 + kLdsCh <= C) {
+            // Whole blocks, kLdsAhead at a time, with that many blocks of indices in flight per wave.  Every slot of the ring has
+            // its own registers and is refilled right after it is read, and nothing in the body is conditional: with a branch
+            // around the loads or the stores the compiler emits s_waitcnt vmcnt(0) at the head of EVERY block, and a block's
+            // lookups wait for the stores of the block before (measured with the stores switched off: 346 of 552 us were the
+            // rest, the two did not overlap at all).  Like this the drain comes once per kLdsAhead blocks: Kodak-24 x 32 Z_hat
+            // 510 -> 456 us with two blocks (four: 548, eight: 584 -- longer bodies, more registers).
+            uint2 qa[kLdsAhead];
 #pragma unroll
-                        for (int n = 1; n < N1; ++n) x = lvl == n ? llv[n] : x;
-                    }
-                    rw[j] = x;
+            for (int i = 0; i < kLdsAhead; ++i) qa[i] = load4(r0 + (long)i * kLdsRows);
+            for (; r0 + (long)kLdsAhead * kLdsRows <= r_end; r0 += (long)kLdsAhead * kLdsRows) {
+#pragma unroll
+                for (int i = 0; i < kLdsAhead; ++i) {
+                    const uint2 q2 = qa[i];
+                    qa[i] = load4(r0 + (long)(kLdsAhead + i) * kLdsRows);
+                    block(r0 + (long)i * kLdsRows, q2, std::true_type{});
                 }
             }
-            auto emit = [&](const float (&val)[4], float *__restrict__ out) {
-                float *tile = tiles + flip * (kLdsCh * kLdsPitch);
-                flip ^= 1;                                      // the tile written two emits ago is free again: a barrier lies between
-                *reinterpret_cast<float4 *>(tile + w * kLdsPitch + ((4 * lane) ^ ((w & 4) << 2))) = make_float4(val[0], val[1], val[2], val[3]);
-                __syncthreads();
-                const int row = threadIdx.x >> 2, g = threadIdx.x & 3, ch4 = g * 4;
-                const int rs = row ^ ((g & 1) << 4);            // (ch4 & 4) << 2: the flip of this channel group's rows
-                const long rr = r0 + row;
-                if (rr < r_end && c0 + ch4 < C)                  // C % 4 == 0: four channels are inside or outside together
-                    *reinterpret_cast<float4 *>(out + (long)l * E + rr * C + c0 + ch4) =
-                        make_float4(tile[ch4 * kLdsPitch + rs], tile[(ch4 + 1) * kLdsPitch + rs], tile[(ch4 + 2) * kLdsPitch + rs],
-                                    tile[(ch4 + 3) * kLdsPitch + rs]);
-            };
-            emit(v, out_a);
-            if (out_raw) emit(rw, out_raw);
         }
+        for (; r0 < r_end; r0 += kLdsRows) block(r0, load4(r0), std::false_type{});       // the ragged rest
     }
 }
 
@@ -330,14 +337,14 @@ size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 // LDS passes (k_lookup_lds) for the outputs they pay for; returns through *did_z / *did_nb which outputs they produced.
 template <int N>
-int lookup_lds_passes(const uint16_t *idx, int64_t B, int32_t C, int32_t L, const float *tab_sorted, const float *level_len,
-                      const float *models, float *out_z, void *out_raw, float *out_nb, bool *did_z, bool *did_nb, hipStream_t st) {
+int lookup_lds_passes(const uint16_t *idx, int64_t B, int32_t C, int32_t L, const float *tab_sorted, const float *models,
+                      float *out_z, float *out_nb, bool *did_z, bool *did_nb, hipStream_t st) {
     *did_z = *did_nb = false;
     if constexpr (N > 10) {
         return VBQ_OK;
     } else {
         static const int mode = [] { const char *e = getenv("VBQ_LOOKUP_LDS"); return e ? atoi(e) : -1; }();   // A/B: 0 never, 1 always
-        const uintptr_t al = reinterpret_cast<uintptr_t>(out_z) | reinterpret_cast<uintptr_t>(out_raw) | reinterpret_cast<uintptr_t>(out_nb);
+        const uintptr_t al = reinterpret_cast<uintptr_t>(out_z) | reinterpret_cast<uintptr_t>(out_nb);
         if (mode == 0 || B % 4 != 0 || C % 4 != 0 || (al & 15) != 0 || (reinterpret_cast<uintptr_t>(idx) & 7) != 0) return VBQ_OK;
         constexpr int TP = table_size(N);
         const size_t lds = sizeof(float) * (size_t)(((kLdsCh * TP + 3) & ~3) + 2 * kLdsCh * kLdsPitch);
@@ -360,14 +367,14 @@ int lookup_lds_passes(const uint16_t *idx, int64_t B, int32_t C, int32_t L, cons
             splits = (B + per - 1) / per;
             VBQ_REQUIRE(splits <= 65535, VBQ_ERR_UNSUPPORTED, "vbq_gather_latents_u16: grid too large");
             hipLaunchKernelGGL((k_lookup_lds<N>), dim3((unsigned)groups, (unsigned)splits), dim3(1024), lds, st, idx, (long)B, (int)C, (int)L,
-                               tab_sorted, 0, level_len, out_z, static_cast<float *>(out_raw), (int)(level_len == nullptr), (long)per);
+                               tab_sorted, 0, out_z, (long)per);
             VBQ_CHECK_LAUNCH("lookup_lds (sorted table)");
             *did_z = true;
         }
         if (want_nb) {
             VBQ_REQUIRE(L <= 65535, VBQ_ERR_UNSUPPORTED, "vbq_gather_latents_u16: grid too large");
             hipLaunchKernelGGL((k_lookup_lds<N>), dim3((unsigned)groups, (unsigned)L), dim3(1024), lds, st, idx, (long)B, (int)C, (int)L,
-                               models, 1, nullptr, out_nb, static_cast<float *>(nullptr), 0, (long)B);
+                               models, 1, out_nb, (long)B);
             VBQ_CHECK_LAUNCH("lookup_lds (entropy models)");
             *did_nb = true;
         }
@@ -382,7 +389,7 @@ int gather_latents(const uint16_t *idx, int64_t B, int32_t C, int32_t L, int32_t
         int rc = VBQ_OK;
 #define VBQ_DISPATCH_N(NN)                                                                                              \
     case NN:                                                                                                            \
-        rc = lookup_lds_passes<NN>(idx, B, C, L, tab_sorted, level_len, models, out_z, out_raw, out_nb, &did_z, &did_nb, st); \
+        rc = lookup_lds_passes<NN>(idx, B, C, L, tab_sorted, models, out_z, out_nb, &did_z, &did_nb, st);             \
         break;
         switch (N) {
             VBQ_FOR_EACH_N(VBQ_DISPATCH_N)
@@ -390,7 +397,7 @@ int gather_latents(const uint16_t *idx, int64_t B, int32_t C, int32_t L, int32_t
         }
 #undef VBQ_DISPATCH_N
         if (rc != VBQ_OK) return rc;
-        if (did_z) { out_z = nullptr; out_raw = nullptr; }
+        if (did_z) out_z = nullptr;                            // (raw_num_bits needs no table worth the LDS: the generic pass writes it at its 5 TB/s)
         if (did_nb) out_nb = nullptr;
         if (!out_z && !out_raw && !out_nb && !out_idx) return VBQ_OK;
     }
