@@ -112,35 +112,44 @@ k_hist_flat(const uint16_t *__restrict__ idx, long n_per_ch, long ch_stride, int
     // first stage is issued before the bins are cleared.  "full": every lane of the wave has all U loads.
     constexpr int U = VBQ_HIST_U;
     auto full = [&](long qq, int n) { return (qq - lane) + 63 + (long)(n - 1) * stride < noct; };
+    // STAGES of U loads that every lane of this wave has (wave-uniform): stage s reads octets q0 + (s U + u) stride.  The loop
+    // over them is written on that count, with NO condition around a load: with `if (haveB) load B` the compiler cannot tell
+    // whether B is in flight, waits with vmcnt(1) / vmcnt(0) for A -- i.e. for B as well -- and the two register stages take
+    // turns instead of overlapping (the same effect cost k_lookup_lds 10 %, EXPERIMENTS.md round 4).
+    const long wq = q - lane;
+    const long room = noct - 64 - wq - (long)(U - 1) * stride;
+    const long stages = room >= 0 ? room / ((long)U * stride) + 1 : 0;
     uint4 A[U], B[U];
-    bool haveA = full(q, U);
-    if (haveA) {
+    auto load_stage = [&](uint4 (&R)[U]) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) A[u] = *reinterpret_cast<const uint4 *>(src + (q + u * stride) * 8);
+        for (int u = 0; u < U; ++u) R[u] = *reinterpret_cast<const uint4 *>(src + (q + u * stride) * 8);
         q += U * stride;
-    }
+    };
+    if (stages > 0) load_stage(A);
 #pragma unroll
     for (int r = 0; r < 2048 / kHistThreads; ++r)                                                  // 32 KB
         reinterpret_cast<uint4 *>(h)[(int)threadIdx.x + r * kHistThreads] = make_uint4(0, 0, 0, 0);
     __syncthreads();
-    while (haveA) {
-        const bool haveB = full(q, U);
-        if (haveB) {
+    if (stages > 0) {
+        const long pairs = (stages - 1) / 2;                    // iterations in which BOTH refills exist
+        for (long p = 0; p < pairs; ++p) {
+            load_stage(B);
 #pragma unroll
-            for (int u = 0; u < U; ++u) B[u] = *reinterpret_cast<const uint4 *>(src + (q + u * stride) * 8);
-            q += U * stride;
+            for (int u = 0; u < U; ++u) hist_add8<N, kHistCopies>(h, A[u]);
+            load_stage(A);
+#pragma unroll
+            for (int u = 0; u < U; ++u) hist_add8<N, kHistCopies>(h, B[u]);
         }
+        if (stages - (2 * pairs + 1) > 0) {                     // one more stage after the one A holds
+            load_stage(B);
 #pragma unroll
-        for (int u = 0; u < U; ++u) hist_add8<N, kHistCopies>(h, A[u]);
-        if (!haveB) break;
-        haveA = full(q, U);
-        if (haveA) {
+            for (int u = 0; u < U; ++u) hist_add8<N, kHistCopies>(h, A[u]);
 #pragma unroll
-            for (int u = 0; u < U; ++u) A[u] = *reinterpret_cast<const uint4 *>(src + (q + u * stride) * 8);
-            q += U * stride;
+            for (int u = 0; u < U; ++u) hist_add8<N, kHistCopies>(h, B[u]);
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) hist_add8<N, kHistCopies>(h, A[u]);
         }
-#pragma unroll
-        for (int u = 0; u < U; ++u) hist_add8<N, kHistCopies>(h, B[u]);
     }
     for (; full(q, 1); q += stride) hist_add8<N, kHistCopies>(h, *reinterpret_cast<const uint4 *>(src + q * 8));
     for (; q < noct; q += stride) {
