@@ -840,3 +840,33 @@ def test_channel_last_above_the_old_transpose_limit():
         assert np.array_equal(idx[:, s:s + 1000].cpu().numpy(), want)
     planes = vbq_amd.quantize(mu, sg, [0.5, 4.0], table=tab, out_layout="planes")
     assert torch.equal(ops.transpose_planes(planes), idx)
+
+
+def test_compress_latents_large_batch_through_the_class():
+    """A batch large enough for the LDS-table lookups (k_lookup_lds: Z_hat and num_bits; raw_num_bits from the tile kernel) through
+    ChannelwisePriorCDFQuantizer: build the entropy models on 4 096 x 8 latents, compress the same batch as one [4, 32, 32, 8]
+    tensor, compare all three outputs with the oracle's compress_latents."""
+    from vbq_amd import ChannelwisePriorCDFQuantizer, priors
+    rng = np.random.default_rng(77)
+    C, B = 8, 4096
+    ch_std = np.exp(rng.uniform(np.log(0.3), np.log(3.0), C))
+    q = ChannelwisePriorCDFQuantizer(C, N)
+    q.build_code_points(priors.FactoredGaussianPrior(np.zeros(C), ch_std))
+    orc = O.ChannelwiseOracle(C, N)
+    orc.build_code_points(O.factored_gaussian_icdf(np.zeros(C), ch_std))
+    mu = (rng.standard_normal((B, C)) * ch_std).astype(np.float32)
+    logvars = rng.normal(-4, 1.0, (B, C)).astype(np.float32)
+    stds = (torch.exp(torch.from_numpy(logvars).cuda()) ** 0.5).cpu().numpy()
+    lambs = list(2.0 ** np.linspace(-8, 7, 16))                     # post_process.py:115
+    lam32 = [np.float32(l) for l in lambs]
+    q.build_entropy_models_from_latents(mu, stds, lambs, 1)
+    orc.build_entropy_models(mu, stds, lam32, add_n_smoothing=1)
+    out = q.compress_latents(mu.reshape(4, 32, 32, C), logvars.reshape(4, 32, 32, C), lambs, return_np=False)
+    assert q.entropy_models.on_device
+    ref = orc.compress_latents(mu, stds, lam32)
+    for lamb, l32 in zip(lambs, lam32):
+        for key in ("Z_hat", "raw_num_bits", "num_bits"):
+            got = out[key][lamb]
+            assert tuple(got.shape) == (4, 32, 32, C)
+            assert np.array_equal(got.cpu().numpy().reshape(B, C), ref[key][l32]), (key, lamb)
+    assert np.array_equal(q.entropy_models[lambs[3]], orc.entropy_models[lam32[3]])
