@@ -362,6 +362,27 @@ int vbq_compress_latents_f32(const float *d_means_bc, const float *d_spread_bc, 
                              float *d_out_num_bits, void *d_workspace, size_t workspace_bytes, void *stream);
 
 /* ----------------------------------------------------------------------------------
+ * The whole two-pass build of ChannelwisePriorCDFQuantizer.build_entropy_models (quantizer.py:82-150) on ONE GPU as one C call
+ * = six stream-ordered launches, nothing waits for the host (sharded builds all-reduce between the pieces and call them one by
+ * one: INTEGRATION.md):
+ *     planes (d_spread_bc / spread_kind as for vbq_prep_planes_f32)                                  quantizer.py:87-92
+ *     pass 1   vbq_level_counts_f32 with raw lengths -> d_level_counts [n_lambda][n_ch][N+1] (int64, assigned)   :96-105
+ *     lengths  d_raw_models = lut_levels[count], d_level_len = n + lut_levels[count]   (f32 [n_lambda][n_ch][N+1])   :105-112, 171-175
+ *     pass 2   vbq_quantize_f32 with d_level_len; vbq_histogram_models_u16 -> d_counts [n_lambda][n_ch][T] (int64, or int32 with
+ *              counts_are_i32; assigned) and d_models = lut_ranks[count] (f32 [n_lambda][n_ch][T]; both NULL: no model table)   :119-146
+ *   d_lut_levels / d_lut_ranks: the tabulated -log2 of the smoothed frequencies for every possible count 0 .. n_rows, built by the
+ *   caller with the reference's own NumPy float32 operations (vbq_code_lengths_from_counts): n_lut >= n_rows + 1 entries each.
+ *   Workspace: vbq_build_entropy_models_workspace_bytes() bytes of device memory, 256-byte aligned (planes, index planes, solve).
+ * ---------------------------------------------------------------------------------- */
+size_t vbq_build_entropy_models_workspace_bytes(int64_t n_rows, int32_t n_ch, int32_t n_lambda, int32_t N);
+int vbq_build_entropy_models_f32(const float *d_means_bc, const float *d_spread_bc, int32_t spread_kind, int64_t n_rows,
+                                 int32_t n_ch, const float *d_table_lm, const double *h_lambdas, int32_t n_lambda,
+                                 int32_t N, const float *d_lut_levels, int64_t n_lut_levels, const float *d_lut_ranks,
+                                 int64_t n_lut_ranks, int64_t *d_level_counts, float *d_level_len, float *d_raw_models,
+                                 void *d_counts, int32_t counts_are_i32, float *d_models, void *d_workspace,
+                                 size_t workspace_bytes, void *stream);
+
+/* ----------------------------------------------------------------------------------
  * K4  BMSHJ2018 prior (learned_prior.py).  Parameters are the EFFECTIVE ones --
  *     softplus(matrix_i), bias_i, tanh(factor_i) -- packed per channel as
  *       [ M0(3x1) b0(3) f0(3) | M1(3x3) b1(3) f1(3) | M2(3x3) b2(3) f2(3) | M3(1x3) b3(1) ]

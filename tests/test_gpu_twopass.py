@@ -315,6 +315,20 @@ def test_integration_md_sequence_through_ctypes_only():
         assert np.array_equal(nb[i].cpu().numpy(), ref["num_bits"][k])
     assert h.vbq_compress_latents_f32(p(means), p(var), 1, Bi, Cc, p(table), p(table_sorted), p(level_len), p(models), lamc, L, N,
                                       p(z), p(raw), p(nb), p(ws2), nws2 - 1, st) != 0        # a short workspace is refused
+    # ... and the whole build again as ONE C call on the channel-last latents (vbq_build_entropy_models_f32): the same tables
+    mu_bc, sg_bc = torch.from_numpy(mu_h).to(dev_), torch.from_numpy(sg_h).to(dev_)
+    lc2, ll2, rm2 = torch.full_like(level_counts, -1), torch.zeros_like(level_len), torch.zeros_like(raw_models)
+    cnt2 = torch.full((L, Cc, T), -1, dtype=torch.int32, device=dev_)
+    md2 = torch.zeros_like(models)
+    nws3 = h.vbq_build_entropy_models_workspace_bytes(B, Cc, L, N)
+    ws3 = torch.empty(nws3, dtype=torch.uint8, device=dev_)
+    assert h.vbq_build_entropy_models_f32(p(mu_bc), p(sg_bc), 0, B, Cc, p(table), lamc, L, N, p(d_lut1), B + 1, p(d_lut2), B + 1,
+                                          p(lc2), p(ll2), p(rm2), p(cnt2), 1, p(md2), p(ws3), nws3, st) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(lc2, level_counts) and torch.equal(ll2, level_len) and torch.equal(rm2, raw_models)
+    assert torch.equal(cnt2.to(torch.int64), counts) and torch.equal(md2, models)
+    assert h.vbq_build_entropy_models_f32(p(mu_bc), p(sg_bc), 0, B, Cc, p(table), lamc, L, N, p(d_lut1), B, p(d_lut2), B + 1,
+                                          p(lc2), p(ll2), p(rm2), p(cnt2), 1, p(md2), p(ws3), nws3, st) != 0   # a table shorter than B + 1
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -505,3 +505,61 @@ extern "C" int vbq_compress_latents_f32(const float *d_means_bc, const float *d_
     return vbq_gather_latents_u16(idx, n_rows, n_ch, n_lambda, N, d_table_sorted, d_level_len, d_models, d_out_zhat, d_out_raw_bits,
                                   d_out_num_bits, nullptr, stream);
 }
+
+// ---------------------------------------------------------------------------- the whole two-pass build in one C call
+// ChannelwisePriorCDFQuantizer.build_entropy_models (quantizer.py:82-150) on one GPU, as vbq_amd.pipeline.EntropyModelBuild enqueues
+// it: planes -> pass 1 (solve with raw lengths + bit-length histogram) -> "n + overhead" table -> pass 2 (solve with corrected
+// lengths, rank histogram assigned + entropy models looked up in its flush).  Stream-ordered, nothing waits for the host.
+extern "C" size_t vbq_build_entropy_models_workspace_bytes(int64_t n_rows, int32_t n_ch, int32_t n_lambda, int32_t N) {
+    return vbq_compress_latents_workspace_bytes(n_rows, n_ch, n_lambda, N);      // the same three pieces: planes, index planes, solve
+}
+
+extern "C" int vbq_build_entropy_models_f32(const float *d_means_bc, const float *d_spread_bc, int32_t spread_kind, int64_t n_rows,
+                                            int32_t n_ch, const float *d_table_lm, const double *h_lambdas, int32_t n_lambda,
+                                            int32_t N, const float *d_lut_levels, int64_t n_lut_levels, const float *d_lut_ranks,
+                                            int64_t n_lut_ranks, int64_t *d_level_counts, float *d_level_len, float *d_raw_models,
+                                            void *d_counts, int32_t counts_are_i32, float *d_models, void *d_workspace,
+                                            size_t workspace_bytes, void *stream) {
+    using namespace vbq;
+    VBQ_REQUIRE(n_rows >= 1 && n_ch >= 1 && n_lambda >= 1 && N >= 0 && N <= 15, VBQ_ERR_INVALID_ARGUMENT,
+                "vbq_build_entropy_models_f32: bad sizes");
+    VBQ_REQUIRE(d_lut_levels && n_lut_levels > n_rows && d_level_counts && d_level_len && d_raw_models && d_counts,
+                VBQ_ERR_INVALID_ARGUMENT, "vbq_build_entropy_models_f32: null pointer argument, or a code-length table shorter than n_rows + 1");
+    VBQ_REQUIRE((d_models == nullptr) == (d_lut_ranks == nullptr) && (!d_lut_ranks || n_lut_ranks > n_rows), VBQ_ERR_INVALID_ARGUMENT,
+                "vbq_build_entropy_models_f32: d_models and d_lut_ranks go together (n_rows + 1 entries)");
+    const size_t need = vbq_build_entropy_models_workspace_bytes(n_rows, n_ch, n_lambda, N);
+    VBQ_REQUIRE(d_workspace && workspace_bytes >= need, VBQ_ERR_WORKSPACE,
+                "vbq_build_entropy_models_f32: workspace of %zu bytes given, %zu needed", workspace_bytes, need);
+    VBQ_REQUIRE((reinterpret_cast<uintptr_t>(d_workspace) & 255) == 0, VBQ_ERR_INVALID_ARGUMENT,
+                "vbq_build_entropy_models_f32: workspace must be 256-byte aligned");
+    const size_t E = (size_t)n_rows * (size_t)n_ch;
+    const int64_t N1 = N + 1;
+    char *w = static_cast<char *>(d_workspace);
+    float *mu_cb = reinterpret_cast<float *>(w);
+    w += align256(E * sizeof(float));
+    float *sg_cb = reinterpret_cast<float *>(w);
+    w += align256(E * sizeof(float));
+    uint16_t *idx = reinterpret_cast<uint16_t *>(w);
+    w += align256((size_t)n_lambda * E * sizeof(uint16_t));
+    const size_t qws = vbq_quantize_workspace_bytes(n_ch, n_lambda, N);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    int rc = vbq_prep_planes_f32(d_means_bc, d_spread_bc, spread_kind, n_rows, n_ch, mu_cb, sg_cb, stream);
+    if (rc != VBQ_OK) return rc;
+    hipError_t e = hipMemsetAsync(d_level_counts, 0, sizeof(int64_t) * (size_t)n_lambda * (size_t)n_ch * (size_t)N1, st);
+    if (e != hipSuccess) {
+        set_error("vbq_build_entropy_models_f32: hipMemsetAsync: %s", hipGetErrorString(e));
+        return VBQ_ERR_LAUNCH;
+    }
+    // pass 1 (quantizer.py:96-105): raw lengths -> histogram of the winners' bit levels
+    rc = vbq_level_counts_f32(mu_cb, sg_cb, n_rows, n_ch, VBQ_LAYOUT_CB, d_table_lm, nullptr, h_lambdas, n_lambda, N, d_level_counts, w, qws, stream);
+    if (rc != VBQ_OK) return rc;
+    // :105-112, 171-175: -log2 of the smoothed frequencies (tabulated), "n + overhead"
+    rc = vbq_code_lengths_from_counts(d_level_counts, 0, (int64_t)n_lambda * n_ch * N1, d_lut_levels, n_lut_levels, (int32_t)N1, d_level_len,
+                                      d_raw_models, stream);
+    if (rc != VBQ_OK) return rc;
+    // pass 2 (:119-146): corrected lengths -> rank indices -> histogram (+ entropy models in its flush)
+    rc = vbq_quantize_f32(mu_cb, sg_cb, n_rows, n_ch, VBQ_LAYOUT_CB, d_table_lm, d_level_len, h_lambdas, n_lambda, N, VBQ_MODE_F32, idx, nullptr,
+                          nullptr, w, qws, stream);
+    if (rc != VBQ_OK) return rc;
+    return vbq_histogram_models_u16(idx, n_rows, n_ch, n_lambda, N, d_counts, counts_are_i32, d_lut_ranks, n_lut_ranks, d_models, stream);
+}

@@ -155,8 +155,8 @@ class EntropyModelBuild:
                     buf.clear()
                 t = buf[key] = make()
             return t
-        self.idx = kept(("idx", L, C, self.rows, str(self.dev)),
-                        lambda: torch.empty((L, C, self.rows), dtype=torch.uint16, device=self.dev))
+        self._kept = kept
+        self._idx = None                      # the index planes [L, C, rows], taken (from `buffers`) when a staged pass needs them
         self.level_counts = torch.empty((L, C, N1), dtype=torch.int64, device=self.dev)      # zeroed at the head of every pass 1
         # two rank-histogram buffers when sharded: step i's all-reduce runs while step i+1 fills the other one
         # (pass 2 assigns every bin, or zeroes the buffer itself before it accumulates: no fill here -- 67 MB at C = 256)
@@ -222,6 +222,46 @@ class EntropyModelBuild:
                 payload = r.payload_bytes(self.counts) if r is not None else self.counts.numel() * self.counts.element_size()
             reserved_workgroups = 64 if payload >= (4 << 20) else 0
         self.reserved_workgroups = int(reserved_workgroups)
+
+    @property
+    def idx(self) -> torch.Tensor:
+        if self._idx is None:
+            L, C = self.L, self.C
+            self._idx = self._kept(("idx", L, C, self.rows, str(self.dev)),
+                                   lambda: torch.empty((L, C, self.rows), dtype=torch.uint16, device=self.dev))
+        return self._idx
+
+    # ---------------------------------------------------------------- the whole build as one C call
+    @property
+    def one_call_ok(self) -> bool:
+        """vbq_build_entropy_models_f32 applies: one GPU, both -log2 steps tabulated (or no model table wanted), no chunking."""
+        return (self.world == 1 and self.side is None and self.lut1 is not None and
+                (self.models is None or self.lut2 is not None) and self.timers is None)
+
+    def run_one_call(self, means_bc: torch.Tensor, spread_bc: torch.Tensor, spread: str = "sigma"):
+        """The whole alternation on channel-last latents [rows, C] in ONE C call (planes, pass 1, length table, pass 2, histogram
+        + models): the same launches as `run()` behind one ctypes call.  spread: what spread_bc holds ('sigma' | 'variance' |
+        'logvar', see ops.prep_planes)."""
+        if not self.one_call_ok:
+            raise VBQError("run_one_call: this build needs the staged form (sharded, chunked, timed, or a -log2 step that is not tabulated)")
+        means_bc = ops._dev(means_bc, torch.float32, "means")
+        spread_bc = ops._dev(spread_bc, torch.float32, "spread")
+        if tuple(means_bc.shape) != (self.rows, self.C) or means_bc.shape != spread_bc.shape:
+            raise ValueError(f"expected two [{self.rows}, {self.C}] tensors, got {tuple(means_bc.shape)} / {tuple(spread_bc.shape)}")
+        h = ops._lib.lib()
+        wsb = h.vbq_build_entropy_models_workspace_bytes(self.rows, self.C, self.L, self.N)
+        ws = self._kept(("ws_build", self.L, self.C, self.rows, self.N, str(self.dev)),
+                        lambda: torch.empty(max(wsb, 256), dtype=torch.uint8, device=self.dev))
+        self._set_launch_policy()
+        fused = self.models is not None
+        ops._lib.check(h.vbq_build_entropy_models_f32(
+            ops._ptr(means_bc), ops._ptr(spread_bc), ops._spread_kind(spread), self.rows, self.C, ops._ptr(self.table),
+            ops._doubles(self.lambdas), self.L, self.N, ops._ptr(self.lut1), self.lut1.numel(),
+            ops._ptr(self.lut2) if fused else None, self.lut2.numel() if fused else 0, ops._ptr(self.level_counts),
+            ops._ptr(self.level_len), ops._ptr(self.raw_models), ops._ptr(self.counts), int(self.counts.dtype == torch.int32),
+            ops._ptr(self.models) if fused else None, ops._ptr(ws), ws.numel(), ops._stream(means_bc)), "vbq_build_entropy_models_f32")
+        self._models_current = fused
+        return self
 
     # ---------------------------------------------------------------- stages
     def _set_launch_policy(self):

@@ -422,25 +422,33 @@ class ChannelwisePriorCDFQuantizer:
         from .pipeline import EntropyModelBuild
         lambs = list(lambs)
         N, C = self.max_bits_per_coord, self.num_channels
-        mu_cb, sg_cb = self._prep(batch_means, batch_stds, spread)
-        B = mu_cb.shape[1]
+        mu_bc, sp_bc = self._batch_dev(batch_means, batch_stds)
+        if getattr(self, "validate_inputs", False):
+            ops.check_inputs(mu_bc.contiguous(), (sp_bc if spread == "sigma" else torch.exp(sp_bc) ** 0.5).contiguous())
+        B = mu_bc.shape[0]
         B_global, distributed = B, self.process_group is not None
         if distributed:
             import torch.distributed as dist
             t = torch.tensor([B], dtype=torch.int64, device=self.device)
             dist.all_reduce(t, group=self.process_group)
             B_global = int(t.item())
-        # the index planes, the solve's workspace and the -log2 tables are kept between builds of one shape; the OUTPUT
-        # tensors are new every time (the dicts of an earlier build keep theirs)
+        # the index planes, the workspaces and the -log2 tables are kept between builds of one shape; the OUTPUT tensors are
+        # new every time (the dicts of an earlier build keep theirs)
         build = EntropyModelBuild(B, C, [float(l) for l in lambs], self._table_dev(), N=N, add_n_smoothing=add_n_smoothing,
                                   global_rows=B_global, distributed=distributed, group=self.process_group,
                                   counts_dtype=torch.int32 if B_global < 2 ** 31 else torch.int64, keep_models=self._strict,
                                   buffers=self._dev_cache.setdefault("_build_buffers", {}))
         self.raw_code_length_entropy_models = None
-        build.pass1(mu_cb, sg_cb, None)
-        level_len, raw_models = build.lengths()
-        # pass 2: corrected lengths -> per-channel histogram of the code points (:118-148)
-        _, counts = build.pass2(mu_cb, sg_cb, level_len)
+        if build.one_call_ok and B > 0:
+            # one GPU, tabulated -log2: planes, both passes, the histogram and the models behind ONE C call
+            build.run_one_call(mu_bc, sp_bc, spread)
+            level_len, raw_models, counts = build.level_len, build.raw_models, build.counts
+        else:
+            mu_cb, sg_cb = ops.prep_planes(mu_bc, sp_bc, spread=spread)
+            build.pass1(mu_cb, sg_cb, None)
+            level_len, raw_models = build.lengths()
+            # pass 2: corrected lengths -> per-channel histogram of the code points (:118-148)
+            _, counts = build.pass2(mu_cb, sg_cb, level_len)
         models_dev = build.finish_models()
         self._add_n_smoothing = add_n_smoothing
         self._dev_cache.pop("entropy_models", None)
