@@ -11,7 +11,9 @@
 //   k_gather_latents    ONE pass over the rank indices [L][C][B]: Z_hat = sorted table[c][q]  (quantizer.py:224-225),
 //                       raw_num_bits = level(q) or level_len[l][c][level(q)] (:171-175,186-188), num_bits =
 //                       entropy_model[l][c][q] (:226-228), all written channel-last [L][B][C] (the np.reshape of :237),
-//                       optionally the indices themselves channel-last.
+//                       optionally the indices themselves channel-last.  From two images up the Z_hat and num_bits lookups
+//                       go to k_lookup_lds (16 channel tables resident in the LDS) and this pass keeps the rest.
+// and, at the end of the file, the whole two-pass build of quantizer.py:82-150 as one C call (vbq_build_entropy_models_f32).
 //
 // The level of rank index q is N - ctz(q + 1) (slot (n, i) <-> rank (2i + 1) 2^(N-n) - 1), so no per-rank length table is
 // built or read.
