@@ -10,7 +10,8 @@
  *     allocated inside a call -- scratch comes from a caller-provided workspace.
  *   - return value: 0 = ok, negative = VBQ_ERR_*; vbq_last_error() gives the text of
  *     the calling thread's most recent failure.
- *   - no global state besides that thread-local error string.
+ *   - no global state besides that thread-local error string (launch policies are per-call arguments; environment
+ *     presets are read once and never written).
  *
  * The reference (mandt-lab/vbq) has no FFI of its own: the boundary it offers is the
  * Python call surface listed in SURVEY.md 8(b).  Each entry point below names the
@@ -42,7 +43,7 @@
 extern "C" {
 #endif
 
-#define VBQ_ABI_VERSION 4
+#define VBQ_ABI_VERSION 5
 
 enum {
     VBQ_OK = 0,
@@ -76,13 +77,22 @@ enum {
 int vbq_abi_version(void);
 const char *vbq_last_error(void);
 
-/* Process-wide launch policy for builds that overlap a collective with the kernels (the rank histogram's all-reduce
- * of step i runs while step i + 1 computes).  The solve kernels run as RESIDENT grids sized to every workgroup slot of the
- * chip; a collective's kernel (RCCL: a few dozen workgroups) takes some of those slots, and a resident workgroup that finds its
- * slot taken starts only after another one has finished all its iterations -- up to twice the kernel time.  With n > 0 the
- * grids are sized to (slots - n), or launched as short-lived workgroups when the (workgroups x channels) grid shape would
- * give up more than a tenth of the chip.  n = 0 (default): every slot.  Also preset by VBQ_RESERVED_WORKGROUPS. */
-int vbq_set_reserved_workgroups(int32_t n);
+/* Launch policy: `reserved_workgroups` (vbq_quantize_rows_f32, vbq_level_counts_f32, vbq_build_entropy_models_f32).
+ * For builds that overlap a collective with the kernels (the rank histogram's all-reduce of step i runs while step
+ * i + 1 computes).  The solve kernels run as RESIDENT grids sized to every workgroup slot of the chip; a collective's kernel (RCCL:
+ * a few dozen workgroups) takes some of those slots, and a resident workgroup that finds its slot taken starts only after another
+ * one has finished all its iterations -- up to twice the kernel time.  With n > 0 the grids of THAT CALL are sized to (slots - n), or
+ * launched as short-lived workgroups when the (workgroups x channels) grid shape would give up more than a tenth of the chip.
+ * n = 0: every slot.  n < 0: the default, 0 unless the environment variable VBQ_RESERVED_WORKGROUPS presets it (read once).  A
+ * per-call argument: the library keeps no mutable launch state, two builds with different policies may run side by side. */
+
+/* The launch shape a solve call would take on the current device -- nothing is launched: h_grid (HOST, int64 [3]) = { workgroups
+ * per channel, channels, 1 when every workgroup is resident from start to end (0: short-lived workgroups) } for
+ * VBQ_GRID_K1 (the fused per-lambda kernel of vbq_quantize_rows_f32) / VBQ_GRID_K1T (the threshold kernel of vbq_level_counts_f32)
+ * on n_rows rows per channel.  A pure function of its arguments and the device's CU count: what makes the launch policy testable. */
+enum { VBQ_GRID_K1 = 0, VBQ_GRID_K1T = 1 };
+int vbq_solve_grid(int32_t kernel, int64_t n_rows, int32_t n_ch, int32_t workgroups_per_cu, int32_t reserved_workgroups,
+                   int64_t *h_grid);
 
 /* Number of GPUs visible / name of device `dev` (for harness output only). */
 int vbq_device_count(void);
@@ -143,14 +153,14 @@ int vbq_n_bit_intervals_f32(const float *d_z_cb, int64_t n_rows, int32_t n_ch, c
  * of the whole tensor): lets the caller cut one pass into chunks and run K2 on chunk j (another stream) while K1
  * works on chunk j + 1.  workgroups_per_cu = 0: default grid (the 4 workgroups per CU that fit, resident from start to
  * end, issue priority rotating over them); 1..5: a resident grid of that many workgroups per CU (at most the 4 that
- * fit; 3 leaves wave slots and LDS for a concurrently running K2).  For planes (VBQ_LAYOUT_CB) the vector path wants
- * row_begin % 8 == 0. */
+ * fit; 3 leaves wave slots and LDS for a concurrently running K2).  reserved_workgroups: see "Launch policy" above
+ * (vbq_quantize_f32 takes the default).  For planes (VBQ_LAYOUT_CB) the vector path wants row_begin % 8 == 0. */
 int vbq_quantize_rows_f32(const float *d_mu, const float *d_sigma, int64_t n_rows, int32_t n_ch,
                           int32_t layout, const float *d_table_lm, const float *d_level_len,
                           const double *h_lambdas, int32_t n_lambda, int32_t N, int32_t mode,
                           uint16_t *d_out_idx, float *d_out_zhat, float *d_out_bits,
                           void *d_workspace, size_t workspace_bytes, int64_t row_begin, int64_t row_end,
-                          int32_t workgroups_per_cu, void *stream);
+                          int32_t workgroups_per_cu, int32_t reserved_workgroups, void *stream);
 
 /* ----------------------------------------------------------------------------------
  * K1t / K1h  Solve + bit-length histogram in one kernel, nothing written per element (K1t: raw lengths at N = 10 without a
@@ -160,12 +170,13 @@ int vbq_quantize_rows_f32(const float *d_mu, const float *d_sigma, int64_t n_row
  *      level of every winner and nothing else.  Same arithmetic and tie rules as vbq_quantize_f32 (VBQ_MODE_F32).
  *   d_level_counts  int64 [n_lambda][n_ch][N+1], ADDED to (zero it first).
  *   layout          VBQ_LAYOUT_CB, VBQ_LAYOUT_BC_TO_CB, or any layout with n_ch == 1.
+ *   reserved_workgroups  see "Launch policy" above (0: every slot).
  *   Returns VBQ_ERR_UNSUPPORTED for lambdas outside [1.9e-12, 1.8e19] (use vbq_quantize_f32 + vbq_histogram_u16).
  * ---------------------------------------------------------------------------------- */
 int vbq_level_counts_f32(const float *d_mu, const float *d_sigma, int64_t n_rows, int32_t n_ch,
                          int32_t layout, const float *d_table_lm, const float *d_level_len,
                          const double *h_lambdas, int32_t n_lambda, int32_t N, int64_t *d_level_counts,
-                         void *d_workspace, size_t workspace_bytes, void *stream);
+                         void *d_workspace, size_t workspace_bytes, int32_t reserved_workgroups, void *stream);
 
 /* Code lengths from counts through a table: out[i] = (level_period ? i % level_period : 0) + lut[counts[i]].
  * Replaces the float32 arithmetic of quantizer.py:105-110 / 141-146 (counts + n -> / sum -> -log2) when the caller
@@ -373,6 +384,7 @@ int vbq_compress_latents_f32(const float *d_means_bc, const float *d_spread_bc, 
  *   d_lut_levels / d_lut_ranks: the tabulated -log2 of the smoothed frequencies for every possible count 0 .. n_rows, built by the
  *   caller with the reference's own NumPy float32 operations (vbq_code_lengths_from_counts): n_lut >= n_rows + 1 entries each.
  *   Workspace: vbq_build_entropy_models_workspace_bytes() bytes of device memory, 256-byte aligned (planes, index planes, solve).
+ *   reserved_workgroups: for both solve passes, see "Launch policy" above (0: every slot -- a single-GPU build has no neighbour).
  * ---------------------------------------------------------------------------------- */
 size_t vbq_build_entropy_models_workspace_bytes(int64_t n_rows, int32_t n_ch, int32_t n_lambda, int32_t N);
 int vbq_build_entropy_models_f32(const float *d_means_bc, const float *d_spread_bc, int32_t spread_kind, int64_t n_rows,
@@ -380,7 +392,7 @@ int vbq_build_entropy_models_f32(const float *d_means_bc, const float *d_spread_
                                  int32_t N, const float *d_lut_levels, int64_t n_lut_levels, const float *d_lut_ranks,
                                  int64_t n_lut_ranks, int64_t *d_level_counts, float *d_level_len, float *d_raw_models,
                                  void *d_counts, int32_t counts_are_i32, float *d_models, void *d_workspace,
-                                 size_t workspace_bytes, void *stream);
+                                 size_t workspace_bytes, int32_t reserved_workgroups, void *stream);
 
 /* ----------------------------------------------------------------------------------
  * K4  BMSHJ2018 prior (learned_prior.py).  Parameters are the EFFECTIVE ones --

@@ -44,7 +44,7 @@ def test_ctypes_binding_matches_header(built_lib):
     from vbq_amd import _lib
     assert sorted(_lib.SIGNATURES) == declared_functions()
     h = _lib.lib()
-    assert h.vbq_abi_version() == 4
+    assert h.vbq_abi_version() == 5
     assert isinstance(h.vbq_device_count(), int)
     # argument validation happens before any device work: callable without a GPU
     assert h.vbq_quantize_workspace_bytes(256, 32, 10) >= 256 * 32 * 11 * 4
@@ -89,11 +89,57 @@ def test_argument_validation_of_the_newer_entry_points(built_lib):
     assert h.vbq_allreduce_hist(None, None, -1, 0, None) == -1 and h.vbq_allreduce_hist(None, None, 0, 0, None) == 0
     assert h.vbq_allreduce_hist(None, None, 5, 1, None) == -1 and b"null pointer" in h.vbq_last_error()
     assert h.vbq_comm_init(None, 2, None, 0) == -1 and h.vbq_comm_unique_id(None) == -1 and h.vbq_comm_destroy(None) == 0
-    assert h.vbq_level_counts_f32(None, None, 4, 1, 0, None, None, None, 1, 10, None, None, 0, None) == -1
-    assert h.vbq_quantize_rows_f32(None, None, 4, 1, 0, None, None, None, 1, 10, 0, None, None, None, None, 0, 3, 2, 0, None) == -1
+    assert h.vbq_level_counts_f32(None, None, 4, 1, 0, None, None, None, 1, 10, None, None, 0, 0, None) == -1
+    assert h.vbq_quantize_rows_f32(None, None, 4, 1, 0, None, None, None, 1, 10, 0, None, None, None, None, 0, 3, 2, 0, 0, None) == -1
     assert b"row range" in h.vbq_last_error()
     assert h.vbq_histogram_rows_u16(None, 4, 1, 0, 1, 10, None, 0, 0, 5, None) == -1 and b"row range" in h.vbq_last_error()
     assert h.vbq_code_lengths_from_counts(None, 0, 3, None, 0, 0, None, None, None) == -1
     assert h.vbq_index_max_u16(None, 0, None, None) == 0 and h.vbq_index_max_u16(None, 4, None, None) == -1
     assert h.vbq_downsample2_f64(None, 1, 0, 4, 1, None, None) == -1
     assert h.vbq_transpose_f32(None, 4, 4, None, None) == -1
+
+
+def test_launch_policy_is_a_per_call_argument_not_process_state(built_lib):
+    """"re-entrant (no globals besides the error string)".  The reserved-slot policy of the resident solve grids is an
+    argument of vbq_quantize_rows_f32 / vbq_level_counts_f32 / vbq_build_entropy_models_f32 (ABI 5; the process-wide setter of
+    ABI 4 is gone) and vbq_solve_grid answers what grid a call takes: a pure function of its arguments -- many threads asking
+    with different policies at the same time each get their own answer."""
+    import ctypes as C
+    import threading
+    from vbq_amd import _lib
+    h = _lib.lib()
+    assert "vbq_set_reserved_workgroups" not in declared_functions() and not hasattr(h, "vbq_set_reserved_workgroups")
+
+    def grid(kernel, rows, n_ch, wg=0, reserved=0):
+        g = (C.c_int64 * 3)()
+        assert h.vbq_solve_grid(kernel, rows, n_ch, wg, reserved, g) == 0, h.vbq_last_error()
+        return tuple(g)
+
+    K1, K1T = 0, 1
+    cus = 256 if h.vbq_device_count() == 0 else None        # without a device the library assumes an MI355X (256 CUs)
+    if cus:
+        # Kodak-24 (36 864 rows x 256 channels): every slot -> 4 resident workgroups per channel; 64 slots reserved -> K1 cannot
+        # shrink by whole rounds of 256 without giving up a quarter of the chip and takes short-lived workgroups, K1t drops to 3
+        assert grid(K1, 36864, 256, 0, 0) == (4, 256, 1) and grid(K1T, 36864, 256, 0, 0) == (4, 256, 1)
+        assert grid(K1, 36864, 256, 0, 64)[2] == 0 and grid(K1T, 36864, 256, 0, 64) == (3, 256, 1)
+        # one code book: the resident grid shrinks by the reserved slots, stays resident
+        a, b = grid(K1, 10 ** 8, 1, 0, 0), grid(K1, 10 ** 8, 1, 0, 64)
+        assert a[2] == b[2] == 1 and a[0] <= 1024 and b[0] <= 960 and b[0] < a[0]
+        # ADVICE r4: WITHOUT a reservation K1t never gives up a workgroup per CU, whatever the channel count
+        assert grid(K1T, 36864, 300, 0, 0) == (3, 300, 1) and grid(K1T, 36864, 300, 0, 64) == (2, 300, 1)
+        # an explicit workgroups_per_cu wins over the reservation heuristics (the chunked form beside K2)
+        assert grid(K1, 36864, 256, 3, 0) == (3, 256, 1)
+    assert h.vbq_solve_grid(7, 10, 1, 0, 0, (C.c_int64 * 3)()) == -1 and b"unknown kernel" in h.vbq_last_error()
+    assert h.vbq_solve_grid(0, 10, 1, 0, 0, None) == -1
+    want = {r: (grid(K1, 36864, 64, 0, r), grid(K1T, 10 ** 7, 1, 0, r)) for r in (0, 8, 64, 200, 700)}
+    bad = []
+
+    def worker(r):
+        for _ in range(300):
+            if (grid(K1, 36864, 64, 0, r), grid(K1T, 10 ** 7, 1, 0, r)) != want[r]:
+                bad.append(r)
+    ts = [threading.Thread(target=worker, args=(r,)) for r in want for _ in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not bad
+    assert len({want[r] for r in want}) >= 3                   # the policies really differ in the grids they give

@@ -442,33 +442,62 @@ def test_notebook_one_beta_negative_or_zero(ops):
 
 
 def test_reserved_workgroups_change_the_grid_not_the_results(ops):
-    """vbq_set_reserved_workgroups (the launch policy beside an overlapped collective): K1 / K1t with slots left free -- a
-    smaller resident grid for few channels, short-lived workgroups for many -- give the same indices and counts."""
+    """The launch policy beside an overlapped collective, a per-call argument since ABI 5 (`reserved_workgroups`): K1 / K1t with
+    slots left free -- a smaller resident grid for few channels, short-lived workgroups for many -- give the same indices and
+    counts, and two threads running solves with DIFFERENT policies at the same time (own streams) each get their own grid
+    and the right answers: there is no process-wide launch state to race on."""
+    import ctypes as C
+    import threading
+    from scipy.stats import norm
     from vbq_amd import _lib
     h = _lib.lib()
     rng = np.random.default_rng(77)
     lam = [float(v) for v in 2.0 ** np.linspace(-8, 7.5, 32)]
-    try:
-        for rows, C in ((300_000, 1), (9000, 64), (2100, 256)):
-            s_c = np.exp(rng.uniform(np.log(0.3), np.log(3.0), C))
-            mu = (rng.standard_normal((C, rows)) * s_c[:, None]).astype(np.float32)
-            sg = np.exp(rng.normal(-2, 0.7, (C, rows))).astype(np.float32)
-            tab = gaussian_tables(s_c) if "gaussian_tables" in globals() else None
-            if tab is None:
-                from scipy.stats import norm
-                xi = np.concatenate([(np.arange(2 ** k) + 0.5) / 2 ** k for k in range(N + 1)])
-                tab = norm.ppf(xi[None, :], scale=s_c[:, None]).astype(np.float32)
-            ll = (np.arange(N + 1, dtype=np.float32) + np.abs(rng.normal(0, 1, (32, C, N + 1)))).astype(np.float32)
-            got = {}
-            for r in (0, 64, 100000):
-                assert h.vbq_set_reserved_workgroups(r) == 0
-                idx = ops.quantize(dev(mu), dev(sg), dev(tab), lam, N=N, level_len=dev(ll), layout="cb")
-                lc = ops.level_counts(dev(mu), dev(sg), dev(tab), lam, N=N, layout="cb")
-                got[r] = (host(idx), host(lc))
-            want = CO.quantize(np.ascontiguousarray(mu.T), np.ascontiguousarray(sg.T), tab, lam, N=N, level_len=ll)
-            assert np.array_equal(got[0][0].transpose(0, 2, 1), want)
-            for r in (64, 100000):
-                assert np.array_equal(got[r][0], got[0][0]) and np.array_equal(got[r][1], got[0][1]), (rows, C, r)
-        assert h.vbq_set_reserved_workgroups(-1) != 0
-    finally:
-        h.vbq_set_reserved_workgroups(0)
+    xi = np.concatenate([(np.arange(2 ** k) + 0.5) / 2 ** k for k in range(N + 1)])
+
+    def grid(kernel, rows, n_ch, reserved):
+        g = (C.c_int64 * 3)()
+        assert h.vbq_solve_grid(kernel, rows, n_ch, 0, reserved, g) == 0
+        return tuple(g)
+
+    cases = []
+    for rows, Cc in ((300_000, 1), (9000, 64), (2100, 256)):
+        s_c = np.exp(rng.uniform(np.log(0.3), np.log(3.0), Cc))
+        mu = (rng.standard_normal((Cc, rows)) * s_c[:, None]).astype(np.float32)
+        sg = np.exp(rng.normal(-2, 0.7, (Cc, rows))).astype(np.float32)
+        tab = norm.ppf(xi[None, :], scale=s_c[:, None]).astype(np.float32)
+        ll = (np.arange(N + 1, dtype=np.float32) + np.abs(rng.normal(0, 1, (32, Cc, N + 1)))).astype(np.float32)
+        got = {}
+        for r in (0, 64, 100000):
+            idx = ops.quantize(dev(mu), dev(sg), dev(tab), lam, N=N, level_len=dev(ll), layout="cb", reserved_workgroups=r)
+            lc = ops.level_counts(dev(mu), dev(sg), dev(tab), lam, N=N, layout="cb", reserved_workgroups=r)
+            got[r] = (host(idx), host(lc))
+        want = CO.quantize(np.ascontiguousarray(mu.T), np.ascontiguousarray(sg.T), tab, lam, N=N, level_len=ll)
+        assert np.array_equal(got[0][0].transpose(0, 2, 1), want)
+        for r in (64, 100000):
+            assert np.array_equal(got[r][0], got[0][0]) and np.array_equal(got[r][1], got[0][1]), (rows, Cc, r)
+        assert grid(0, rows, Cc, 64) != grid(0, rows, Cc, 0) or grid(1, rows, Cc, 64) != grid(1, rows, Cc, 0), (rows, Cc)
+        cases.append((dev(mu), dev(sg), dev(tab), dev(ll), got[0]))
+    with pytest.raises(Exception):
+        ops.quantize(cases[0][0], cases[0][1], cases[0][2], lam, N=N, layout="cb", workgroups_per_cu=9)
+    # two threads, two policies, at the same time
+    torch.cuda.synchronize()
+    errors = []
+
+    def worker(reserved):
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                for _ in range(6):
+                    for mu_d, sg_d, tab_d, ll_d, (want_idx, want_lc) in cases:
+                        idx = ops.quantize(mu_d, sg_d, tab_d, lam, N=N, level_len=ll_d, layout="cb", reserved_workgroups=reserved)
+                        lc = ops.level_counts(mu_d, sg_d, tab_d, lam, N=N, layout="cb", reserved_workgroups=reserved)
+                        st.synchronize()
+                        if not (np.array_equal(host(idx), want_idx) and np.array_equal(host(lc), want_lc)):
+                            errors.append(reserved)
+        except Exception as e:                               # noqa: BLE001 -- reported below
+            errors.append(repr(e))
+    ts = [threading.Thread(target=worker, args=(r,)) for r in (0, 64, 700)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errors, errors

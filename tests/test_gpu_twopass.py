@@ -282,7 +282,7 @@ def test_integration_md_sequence_through_ctypes_only():
     lamc = (C.c_double * L)(*lam)
     p = lambda t: C.c_void_p(t.data_ptr())
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    assert h.vbq_level_counts_f32(p(mu), p(sg), B, Cc, 1, p(table), None, lamc, L, N, p(level_counts), p(ws), nws, st) == 0
+    assert h.vbq_level_counts_f32(p(mu), p(sg), B, Cc, 1, p(table), None, lamc, L, N, p(level_counts), p(ws), nws, 0, st) == 0
     assert h.vbq_code_lengths_from_counts(p(level_counts), 0, L * Cc * (N + 1), p(d_lut1), B + 1, N + 1, p(level_len), p(raw_models), st) == 0
     assert h.vbq_quantize_f32(p(mu), p(sg), B, Cc, 1, p(table), p(level_len), lamc, L, N, 0, p(idx), None, None, p(ws), nws, st) == 0
     assert h.vbq_histogram_models_u16(p(idx), B, Cc, L, N, p(counts), 0, p(d_lut2), B + 1, p(models), st) == 0
@@ -323,12 +323,12 @@ def test_integration_md_sequence_through_ctypes_only():
     nws3 = h.vbq_build_entropy_models_workspace_bytes(B, Cc, L, N)
     ws3 = torch.empty(nws3, dtype=torch.uint8, device=dev_)
     assert h.vbq_build_entropy_models_f32(p(mu_bc), p(sg_bc), 0, B, Cc, p(table), lamc, L, N, p(d_lut1), B + 1, p(d_lut2), B + 1,
-                                          p(lc2), p(ll2), p(rm2), p(cnt2), 1, p(md2), p(ws3), nws3, st) == 0
+                                          p(lc2), p(ll2), p(rm2), p(cnt2), 1, p(md2), p(ws3), nws3, 0, st) == 0
     torch.cuda.synchronize()
     assert torch.equal(lc2, level_counts) and torch.equal(ll2, level_len) and torch.equal(rm2, raw_models)
     assert torch.equal(cnt2.to(torch.int64), counts) and torch.equal(md2, models)
     assert h.vbq_build_entropy_models_f32(p(mu_bc), p(sg_bc), 0, B, Cc, p(table), lamc, L, N, p(d_lut1), B, p(d_lut2), B + 1,
-                                          p(lc2), p(ll2), p(rm2), p(cnt2), 1, p(md2), p(ws3), nws3, st) != 0   # a table shorter than B + 1
+                                          p(lc2), p(ll2), p(rm2), p(cnt2), 1, p(md2), p(ws3), nws3, 0, st) != 0   # a table shorter than B + 1
 
 
 # ---------------------------------------------------------------------------------------------------------------------

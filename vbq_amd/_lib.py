@@ -12,7 +12,7 @@ c_f32p = C.c_void_p      # device pointers travel as integers
 c_u16p = C.c_void_p
 
 OK = 0
-ABI_VERSION = 4
+ABI_VERSION = 5
 LAYOUT_BC, LAYOUT_CB, LAYOUT_BC_TO_CB = 0, 1, 2
 MODE_F32, MODE_F64_SCORE = 0, 1
 BMSHJ_PARAMS_PER_CHANNEL = 43
@@ -22,7 +22,7 @@ COMM_ID_BYTES = 128
 SIGNATURES = {
     "vbq_abi_version": (C.c_int, []),
     "vbq_last_error": (C.c_char_p, []),
-    "vbq_set_reserved_workgroups": (C.c_int, [C.c_int32]),
+    "vbq_solve_grid": (C.c_int, [C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int64)]),
     "vbq_device_count": (C.c_int, []),
     "vbq_device_name": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t]),
     "vbq_quantize_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
@@ -34,10 +34,10 @@ SIGNATURES = {
                                           C.c_void_p]),
     "vbq_quantize_rows_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                         C.POINTER(C.c_double), C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
-                                        C.c_void_p, C.c_void_p, C.c_size_t, C.c_int64, C.c_int64, C.c_int32, C.c_void_p]),
+                                        C.c_void_p, C.c_void_p, C.c_size_t, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
     "vbq_level_counts_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                        C.POINTER(C.c_double), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t,
-                                       C.c_void_p]),
+                                       C.c_int32, C.c_void_p]),
     "vbq_code_lengths_from_counts": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_int64, C.c_int32,
                                                C.c_void_p, C.c_void_p, C.c_void_p]),
     "vbq_histogram_rows_u16": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
@@ -74,7 +74,7 @@ SIGNATURES = {
     "vbq_build_entropy_models_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_void_p,
                                                C.POINTER(C.c_double), C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p,
                                                C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
-                                               C.c_void_p, C.c_size_t, C.c_void_p]),
+                                               C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p]),
     "vbq_argmax_candidates_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64,
                                             C.POINTER(C.c_double), C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                             C.c_void_p, C.c_void_p, C.c_void_p]),

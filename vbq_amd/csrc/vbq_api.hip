@@ -1,5 +1,4 @@
 // C-ABI plumbing: error string, ABI version, device queries.
-#include <atomic>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -34,34 +33,23 @@ int num_cus() {
     }
     return cached[dev];
 }
-// Workgroup slots the resident grids leave free (for a collective's kernel running beside them): process-wide, default 0;
-// VBQ_RESERVED_WORKGROUPS presets it (read once).
-static std::atomic<int> g_reserved{-1};
-int reserved_workgroups() {
-    int v = g_reserved.load(std::memory_order_relaxed);
-    if (v < 0) {
+// Workgroup slots a resident grid leaves free for a kernel of another stream: a PER-CALL argument of the entry points that launch
+// resident grids (vbq_quantize_rows_f32, vbq_level_counts_f32, vbq_build_entropy_models_f32).  A negative argument takes the
+// default, which VBQ_RESERVED_WORKGROUPS presets (read once, never written afterwards: no mutable process state).
+int default_reserved_workgroups() {
+    static const int v = [] {
         const char *e = getenv("VBQ_RESERVED_WORKGROUPS");
-        v = e ? atoi(e) : 0;
-        if (v < 0) v = 0;
-        g_reserved.store(v, std::memory_order_relaxed);
-    }
+        const int n = e ? atoi(e) : 0;
+        return n < 0 ? 0 : n;
+    }();
     return v;
 }
-int64_t resident_slots(int per_cu) {
+int64_t resident_slots(int per_cu, int reserved) {
     const int64_t all = (int64_t)num_cus() * per_cu;
-    const int64_t left = all - reserved_workgroups();
+    const int64_t left = all - (reserved > 0 ? reserved : 0);
     return left < num_cus() ? num_cus() : left;                  // never below one workgroup per CU
 }
 }  // namespace vbq
-
-extern "C" int vbq_set_reserved_workgroups(int32_t n) {
-    if (n < 0) {
-        vbq::set_error("vbq_set_reserved_workgroups: n=%d is negative", n);
-        return VBQ_ERR_INVALID_ARGUMENT;
-    }
-    vbq::g_reserved.store(n, std::memory_order_relaxed);
-    return VBQ_OK;
-}
 
 extern "C" int vbq_abi_version(void) { return VBQ_ABI_VERSION; }
 

@@ -13,10 +13,11 @@ void set_error(const char *fmt, ...);
 // Compute units of the current device (hipDeviceProp_t::multiProcessorCount, cached per device): what the persistent
 // grids are sized by.  256 on MI355X; never hard-coded.
 int num_cus();
-// Workgroup slots of a resident grid with `per_cu` workgroups per CU, minus the slots reserved for a kernel of another stream
-// (vbq_set_reserved_workgroups: the distributed pipeline's overlapped all-reduce), never below one per CU.
-int64_t resident_slots(int per_cu);
-int reserved_workgroups();
+// Workgroup slots of a resident grid with `per_cu` workgroups per CU, minus the `reserved` slots the CALLER leaves to a kernel of
+// another stream (the `reserved_workgroups` argument of the entry points: the distributed pipeline's overlapped all-reduce),
+// never below one per CU.  default_reserved_workgroups(): what a negative argument means -- VBQ_RESERVED_WORKGROUPS, read once.
+int64_t resident_slots(int per_cu, int reserved);
+int default_reserved_workgroups();
 
 #define VBQ_REQUIRE(cond, code, ...)            \
     do {                                        \
@@ -92,12 +93,13 @@ struct Lambdas32 {
 
 // vbq_quantize_fast.hip.  Elements of channel c start at c * ch_stride (n_per_ch of them are processed); E is the
 // distance between the lambda planes of the outputs.  level_counts != NULL selects the counting mode (no element
-// output).  wg_per_cu in 1..5 makes the grid persistent at that many workgroups per CU (0: the default sizing).
+// output).  wg_per_cu in 1..5 makes the grid persistent at that many workgroups per CU (0: the default sizing); `reserved`
+// workgroup slots are left to a kernel of another stream.
 template <int N>
 int launch_quant_fast(const float *mu, const float *sg, int64_t n_per_ch, int64_t ch_stride, int32_t n_ch, const float *table,
                       const Lambdas32 &lam, const float *len, int32_t L, uint16_t *out_idx, float *out_zhat,
                       float *out_bits, int64_t E, int vec_ok,
-                      unsigned long long *level_counts, int wg_per_cu, hipStream_t st);
+                      unsigned long long *level_counts, int wg_per_cu, int reserved, hipStream_t st);
 
 // K1p (vbq_quantize_fast.hip): one to four lambdas per call with exact pruning of the descent; indices only.  Returns 1 when the
 // call is not of that kind (the caller takes launch_quant_fast).  Valid for ANY penalties (literal comparisons only).
@@ -109,7 +111,7 @@ int launch_quant_pruned(const float *mu, const float *sg, int64_t n_per_ch, int6
 // lambda sweep is not eligible (caller falls back to the dense counting kernel).
 int launch_level_counts_hull10(const float *mu, const float *sg, int64_t n_per_ch, int64_t ch_stride, int32_t n_ch,
                                const float *table, const double *lam, int32_t L, int vec_ok,
-                               unsigned long long *level_counts, hipStream_t st);
+                               unsigned long long *level_counts, int reserved, hipStream_t st);
 
 // K1e (vbq_quantize_fast.hip): rank indices of a raw-length lambda sweep from K1t's thresholds; N = 10.  Returns 1 when the
 // sweep is not eligible (caller falls back to launch_quant_fast).

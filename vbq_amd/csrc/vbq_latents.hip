@@ -19,6 +19,8 @@
 // built or read.
 #include <stdlib.h>
 
+#include <atomic>
+
 #include <type_traits>
 
 #include "vbq_common.h"
@@ -355,11 +357,24 @@ int lookup_lds_passes(const uint16_t *idx, int64_t B, int32_t C, int32_t L, cons
         const bool want_z = out_z != nullptr && (mode == 1 || mode == 3 || (mode < 0 && (int64_t)L * B >= kLdsMinLookupsZ));
         const bool want_nb = out_nb != nullptr && (mode == 1 || mode == 2 || (mode < 0 && B >= kLdsMinLookupsNb));
         if (!want_z && !want_nb) return VBQ_OK;
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lookup_lds<N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) {
-            set_error("hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
-            return VBQ_ERR_LAUNCH;
+        // The LDS opt-in of the kernel, once per (device, N): 1 = granted, 2 = refused (a device or partition mode with less LDS
+        // to opt into).  The passes are an optimisation: refused, or with a grid beyond the launch limits, the outputs stay with
+        // the generic kernel, which can always produce them.
+        static std::atomic<signed char> lds_state[64];
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+            (void)hipGetLastError();
+            return VBQ_OK;
         }
+        signed char state = lds_state[dev].load(std::memory_order_relaxed);
+        if (state == 0) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lookup_lds<N>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) (void)hipGetLastError();
+            state = e == hipSuccess ? 1 : 2;
+            lds_state[dev].store(state, std::memory_order_relaxed);
+        }
+        if (state != 1) return VBQ_OK;
         if (want_z) {
             int64_t splits = (2 * (int64_t)num_cus() + groups - 1) / groups;                 // about two workgroups per CU in all
             const int64_t blocks = (B + kLdsRows - 1) / kLdsRows;
@@ -367,14 +382,13 @@ int lookup_lds_passes(const uint16_t *idx, int64_t B, int32_t C, int32_t L, cons
             if (splits < 1) splits = 1;
             const int64_t per = ((blocks + splits - 1) / splits) * kLdsRows;
             splits = (B + per - 1) / per;
-            VBQ_REQUIRE(splits <= 65535, VBQ_ERR_UNSUPPORTED, "vbq_gather_latents_u16: grid too large");
+            if (splits > 65535) return VBQ_OK;                 // (not reachable with ~2 workgroups per CU; the generic kernel serves it)
             hipLaunchKernelGGL((k_lookup_lds<N>), dim3((unsigned)groups, (unsigned)splits), dim3(1024), lds, st, idx, (long)B, (int)C, (int)L,
                                tab_sorted, 0, out_z, (long)per);
             VBQ_CHECK_LAUNCH("lookup_lds (sorted table)");
             *did_z = true;
         }
-        if (want_nb) {
-            VBQ_REQUIRE(L <= 65535, VBQ_ERR_UNSUPPORTED, "vbq_gather_latents_u16: grid too large");
+        if (want_nb && L <= 65535) {
             hipLaunchKernelGGL((k_lookup_lds<N>), dim3((unsigned)groups, (unsigned)L), dim3(1024), lds, st, idx, (long)B, (int)C, (int)L,
                                models, 1, out_nb, (long)B);
             VBQ_CHECK_LAUNCH("lookup_lds (entropy models)");
@@ -521,7 +535,7 @@ extern "C" int vbq_build_entropy_models_f32(const float *d_means_bc, const float
                                             int32_t N, const float *d_lut_levels, int64_t n_lut_levels, const float *d_lut_ranks,
                                             int64_t n_lut_ranks, int64_t *d_level_counts, float *d_level_len, float *d_raw_models,
                                             void *d_counts, int32_t counts_are_i32, float *d_models, void *d_workspace,
-                                            size_t workspace_bytes, void *stream) {
+                                            size_t workspace_bytes, int32_t reserved_workgroups, void *stream) {
     using namespace vbq;
     VBQ_REQUIRE(n_rows >= 1 && n_ch >= 1 && n_lambda >= 1 && N >= 0 && N <= 15, VBQ_ERR_INVALID_ARGUMENT,
                 "vbq_build_entropy_models_f32: bad sizes");
@@ -553,15 +567,16 @@ extern "C" int vbq_build_entropy_models_f32(const float *d_means_bc, const float
         return VBQ_ERR_LAUNCH;
     }
     // pass 1 (quantizer.py:96-105): raw lengths -> histogram of the winners' bit levels
-    rc = vbq_level_counts_f32(mu_cb, sg_cb, n_rows, n_ch, VBQ_LAYOUT_CB, d_table_lm, nullptr, h_lambdas, n_lambda, N, d_level_counts, w, qws, stream);
+    rc = vbq_level_counts_f32(mu_cb, sg_cb, n_rows, n_ch, VBQ_LAYOUT_CB, d_table_lm, nullptr, h_lambdas, n_lambda, N, d_level_counts, w, qws,
+                              reserved_workgroups, stream);
     if (rc != VBQ_OK) return rc;
     // :105-112, 171-175: -log2 of the smoothed frequencies (tabulated), "n + overhead"
     rc = vbq_code_lengths_from_counts(d_level_counts, 0, (int64_t)n_lambda * n_ch * N1, d_lut_levels, n_lut_levels, (int32_t)N1, d_level_len,
                                       d_raw_models, stream);
     if (rc != VBQ_OK) return rc;
     // pass 2 (:119-146): corrected lengths -> rank indices -> histogram (+ entropy models in its flush)
-    rc = vbq_quantize_f32(mu_cb, sg_cb, n_rows, n_ch, VBQ_LAYOUT_CB, d_table_lm, d_level_len, h_lambdas, n_lambda, N, VBQ_MODE_F32, idx, nullptr,
-                          nullptr, w, qws, stream);
+    rc = vbq_quantize_rows_f32(mu_cb, sg_cb, n_rows, n_ch, VBQ_LAYOUT_CB, d_table_lm, d_level_len, h_lambdas, n_lambda, N, VBQ_MODE_F32, idx,
+                               nullptr, nullptr, w, qws, 0, n_rows, 0, reserved_workgroups, stream);
     if (rc != VBQ_OK) return rc;
     return vbq_histogram_models_u16(idx, n_rows, n_ch, n_lambda, N, d_counts, counts_are_i32, d_lut_ranks, n_lut_ranks, d_models, stream);
 }

@@ -372,7 +372,7 @@ template <int N, typename PenT>
 int launch_quantize(const float *mu, const float *sg, int64_t n_rows, int32_t n_ch, int32_t layout,
                     const float *table, const float *level_len, const double *h_lambdas, int32_t L,
                     uint16_t *out_idx, float *out_zhat, float *out_bits, void *ws, int64_t row_begin, int64_t row_end,
-                    unsigned long long *level_counts, int wg_per_cu, hipStream_t st) {
+                    unsigned long long *level_counts, int wg_per_cu, int reserved, hipStream_t st) {
     constexpr int N1 = N + 1;
     const int64_t E = n_rows * (int64_t)n_ch;
     const int64_t n_sub = row_end - row_begin;
@@ -435,7 +435,7 @@ int launch_quantize(const float *mu, const float *sg, int64_t n_rows, int32_t n_
                 // first entropy-model pass (raw lengths, levels only): thresholds instead of a per-lambda loop
                 if (fast_ok && lc_out && !len_c) {
                     const int r = launch_level_counts_hull10(mu_r, sg_r, n_per_ch, ch_stride, n_ch, table, lc.lam, Lc,
-                                                             vec2_ok | (bc_to_cb ? 2 : 0), lc_out, st);
+                                                             vec2_ok | (bc_to_cb ? 2 : 0), lc_out, reserved, st);
                     if (r == VBQ_OK) continue;
                     if (r < 0) return r;
                 }
@@ -461,7 +461,7 @@ int launch_quantize(const float *mu, const float *sg, int64_t n_rows, int32_t n_
             if constexpr (sizeof(PenT) == 4) {
                 if (fast_ok) {
                     const int r = launch_quant_fast<N>(mu_r, sg_r, n_per_ch, ch_stride, n_ch, table, l32, len_c, Lc, oi, oz, ob,
-                                                       E, vec2_ok | (bc_to_cb ? 2 : 0), lc_out, wg_per_cu, st);
+                                                       E, vec2_ok | (bc_to_cb ? 2 : 0), lc_out, wg_per_cu, reserved, st);
                     if (r != VBQ_OK) return r;
                     continue;
                 }
@@ -526,7 +526,7 @@ int quantize_entry(const char *who, const float *d_mu, const float *d_sigma, int
                    const float *d_table_lm, const float *d_level_len, const double *h_lambdas, int32_t n_lambda,
                    int32_t N, int32_t mode, uint16_t *d_out_idx, float *d_out_zhat, float *d_out_bits,
                    void *d_workspace, size_t workspace_bytes, int64_t row_begin, int64_t row_end,
-                   unsigned long long *level_counts, int32_t wg_per_cu, void *stream) {
+                   unsigned long long *level_counts, int32_t wg_per_cu, int32_t reserved_wgs, void *stream) {
     const bool counting = level_counts != nullptr;
     VBQ_REQUIRE(n_rows >= 0 && n_ch >= 1 && n_lambda >= 1, VBQ_ERR_INVALID_ARGUMENT,
                 "%s: bad sizes n_rows=%lld n_ch=%d n_lambda=%d", who, (long long)n_rows, n_ch, n_lambda);
@@ -548,15 +548,16 @@ int quantize_entry(const char *who, const float *d_mu, const float *d_sigma, int
                 workspace_bytes, need);
     if (row_begin == row_end) return VBQ_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int reserved = reserved_wgs < 0 ? default_reserved_workgroups() : reserved_wgs;
 #define VBQ_DISPATCH_N(NN)                                                                                         \
     case NN:                                                                                                       \
         return mode == VBQ_MODE_F32                                                                                \
                    ? launch_quantize<NN, float>(d_mu, d_sigma, n_rows, n_ch, layout, d_table_lm, d_level_len,      \
                                                 h_lambdas, n_lambda, d_out_idx, d_out_zhat, d_out_bits,            \
-                                                d_workspace, row_begin, row_end, level_counts, wg_per_cu, st)      \
+                                                d_workspace, row_begin, row_end, level_counts, wg_per_cu, reserved, st) \
                    : launch_quantize<NN, double>(d_mu, d_sigma, n_rows, n_ch, layout, d_table_lm, d_level_len,     \
                                                  h_lambdas, n_lambda, d_out_idx, d_out_zhat, d_out_bits,           \
-                                                 d_workspace, row_begin, row_end, level_counts, wg_per_cu, st);
+                                                 d_workspace, row_begin, row_end, level_counts, wg_per_cu, reserved, st);
     switch (N) {
         VBQ_FOR_EACH_N(VBQ_DISPATCH_N)
         default:
@@ -575,7 +576,7 @@ extern "C" int vbq_quantize_f32(const float *d_mu, const float *d_sigma, int64_t
                                 size_t workspace_bytes, void *stream) {
     return vbq::quantize_entry("vbq_quantize_f32", d_mu, d_sigma, n_rows, n_ch, layout, d_table_lm, d_level_len, h_lambdas,
                                n_lambda, N, mode, d_out_idx, d_out_zhat, d_out_bits, d_workspace, workspace_bytes, 0,
-                               n_rows, nullptr, 0, stream);
+                               n_rows, nullptr, 0, -1, stream);
 }
 
 extern "C" int vbq_quantize_rows_f32(const float *d_mu, const float *d_sigma, int64_t n_rows, int32_t n_ch,
@@ -583,21 +584,21 @@ extern "C" int vbq_quantize_rows_f32(const float *d_mu, const float *d_sigma, in
                                      const double *h_lambdas, int32_t n_lambda, int32_t N, int32_t mode,
                                      uint16_t *d_out_idx, float *d_out_zhat, float *d_out_bits, void *d_workspace,
                                      size_t workspace_bytes, int64_t row_begin, int64_t row_end,
-                                     int32_t workgroups_per_cu, void *stream) {
+                                     int32_t workgroups_per_cu, int32_t reserved_workgroups, void *stream) {
     return vbq::quantize_entry("vbq_quantize_rows_f32", d_mu, d_sigma, n_rows, n_ch, layout, d_table_lm, d_level_len,
                                h_lambdas, n_lambda, N, mode, d_out_idx, d_out_zhat, d_out_bits, d_workspace, workspace_bytes,
-                               row_begin, row_end, nullptr, workgroups_per_cu, stream);
+                               row_begin, row_end, nullptr, workgroups_per_cu, reserved_workgroups, stream);
 }
 
 extern "C" int vbq_level_counts_f32(const float *d_mu, const float *d_sigma, int64_t n_rows, int32_t n_ch,
                                     int32_t layout, const float *d_table_lm, const float *d_level_len,
                                     const double *h_lambdas, int32_t n_lambda, int32_t N, int64_t *d_level_counts,
-                                    void *d_workspace, size_t workspace_bytes, void *stream) {
+                                    void *d_workspace, size_t workspace_bytes, int32_t reserved_workgroups, void *stream) {
     using namespace vbq;
     VBQ_REQUIRE(n_rows == 0 || d_level_counts, VBQ_ERR_INVALID_ARGUMENT, "vbq_level_counts_f32: null pointer argument");
     return quantize_entry("vbq_level_counts_f32", d_mu, d_sigma, n_rows, n_ch, layout, d_table_lm, d_level_len, h_lambdas,
                           n_lambda, N, VBQ_MODE_F32, nullptr, nullptr, nullptr, d_workspace, workspace_bytes, 0, n_rows,
-                          reinterpret_cast<unsigned long long *>(d_level_counts), 0, stream);
+                          reinterpret_cast<unsigned long long *>(d_level_counts), 0, reserved_workgroups, stream);
 }
 
 extern "C" int vbq_n_bit_intervals_f32(const float *d_z_cb, int64_t n_rows, int32_t n_ch, const float *d_table_lm, int32_t N,

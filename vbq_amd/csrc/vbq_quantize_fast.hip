@@ -1380,11 +1380,9 @@ k_quant_pruned(const float *__restrict__ mu, const float *__restrict__ sg, long 
 
 }  // namespace
 
-template <int N>
-int launch_quant_fast(const float *mu, const float *sg, int64_t n_per_ch, int64_t ch_stride, int32_t n_ch, const float *table,
-                      const Lambdas32 &lam, const float *len, int32_t L, uint16_t *out_idx, float *out_zhat,
-                      float *out_bits, int64_t E, int vec_ok,
-                      unsigned long long *level_counts, int wg_per_cu, hipStream_t st) {
+// The grid of K1 (k_quant_fast) for one launch: workgroups per channel, and whether all of them are resident from start to end.
+// A pure function of the sizes, the device's CU count and the caller's two launch arguments (no process state).
+void quant_fast_grid(int64_t n_per_ch, int32_t n_ch, int wg_per_cu, int reserved, bool counting, int64_t *out_gx, bool *out_resident) {
     const int64_t nquads = (n_per_ch + kFastNE - 1) / kFastNE;
     int64_t gx = (nquads + kFastThreads - 1) / kFastThreads;
     // A RESIDENT grid: 4 workgroups per CU (110 VGPRs: four waves per SIMD; 3 with NE=4) that stay from start to end, every
@@ -1395,22 +1393,22 @@ int launch_quant_fast(const float *mu, const float *sg, int64_t n_per_ch, int64_
     static const bool dynamic_env = [] { const char *e = getenv("VBQ_K1_DYNAMIC"); return e && e[0] == '1'; }();   // A/B switch
     const bool explicit_wgs = wg_per_cu >= 1 && wg_per_cu <= 5;
     const int fit = kFastNE == 4 ? 3 : 4;
-    // Slots reserved for a kernel of another stream (vbq_set_reserved_workgroups: the overlapped all-reduce of a sharded build).
+    // Slots the caller reserves for a kernel of another stream (`reserved_workgroups` of the entry points: the overlapped
+    // all-reduce of a sharded build).
     // A resident workgroup that finds its slot taken starts only when another one has FINISHED ALL its iterations -- up to twice
     // the kernel time (EXPERIMENTS.md, "resident grids beside a collective") -- so the grid is sized to the slots that are left;
     // the grid is (workgroups per channel) x channels, so with many channels that costs whole rounds of n_ch slots: when more
     // than a tenth of the chip would be given up the launch falls back to short-lived workgroups, which lose 8 % alone but
     // only their share of the taken slots beside a collective.
     bool dynamic_grid = dynamic_env;
-    if (!dynamic_grid && !explicit_wgs && reserved_workgroups() > 0) {
+    if (!dynamic_grid && !explicit_wgs && reserved > 0) {
         const int64_t all = (int64_t)num_cus() * fit;
-        const int64_t kept = (resident_slots(fit) / n_ch) * n_ch;
+        const int64_t kept = (resident_slots(fit, reserved) / n_ch) * n_ch;
         if (kept * 10 < all * 9) dynamic_grid = true;
     }
     const int per_cu = explicit_wgs ? (wg_per_cu < fit ? wg_per_cu : fit) : (dynamic_grid ? 5 : fit);
-    int64_t cap = (dynamic_grid && !explicit_wgs ? (int64_t)num_cus() * per_cu * 4 : resident_slots(per_cu)) / n_ch;
+    int64_t cap = (dynamic_grid && !explicit_wgs ? (int64_t)num_cus() * per_cu * 4 : resident_slots(per_cu, reserved)) / n_ch;
     const bool resident = !(dynamic_grid && !explicit_wgs) && (int64_t)n_ch <= (int64_t)num_cus() * per_cu;
-    if (resident) vec_ok |= 4;
     if (cap < 1) cap = 1;
     if (gx > cap) {
         const int64_t iters = gx;
@@ -1432,9 +1430,22 @@ int launch_quant_fast(const float *mu, const float *sg, int64_t n_per_ch, int64_
         // count mode: a 16-bit partial counter (16 words x 2 halves per (lambda, level)) takes at most 64 / 32 lanes x the waves of
         // a workgroup x the elements of a lane per iteration
         constexpr int64_t max_iters = 65000 / ((64 / 32) * (kFastThreads / 64) * kFastNE);
-        if (level_counts && (iters + gx - 1) / gx > max_iters) gx = (iters + max_iters - 1) / max_iters;
+        if (counting && (iters + gx - 1) / gx > max_iters) gx = (iters + max_iters - 1) / max_iters;
     }
     if (gx < 1) gx = 1;
+    *out_gx = gx;
+    *out_resident = resident;
+}
+
+template <int N>
+int launch_quant_fast(const float *mu, const float *sg, int64_t n_per_ch, int64_t ch_stride, int32_t n_ch, const float *table,
+                      const Lambdas32 &lam, const float *len, int32_t L, uint16_t *out_idx, float *out_zhat,
+                      float *out_bits, int64_t E, int vec_ok,
+                      unsigned long long *level_counts, int wg_per_cu, int reserved, hipStream_t st) {
+    int64_t gx = 1;
+    bool resident = false;
+    quant_fast_grid(n_per_ch, n_ch, wg_per_cu, reserved, level_counts != nullptr, &gx, &resident);
+    if (resident) vec_ok |= 4;
     const dim3 grid((unsigned)gx, (unsigned)n_ch), block(kFastThreads);
     static const int dbg = [] { const char *e = getenv("VBQ_FAST_DEBUG"); return e ? atoi(e) : 0; }();
     if (level_counts)
@@ -1518,16 +1529,8 @@ static bool build_hull_sweep(const double *lam, int L, HullSweep &sw) {
     return true;
 }
 
-// Host side of K1t: sort the sweep, check that the bucket table applies (distinct f32 values at least one bucket
-// apart, within 16 octaves), launch.  Returns 1 when the sweep is not eligible (the caller then takes the dense
-// counting kernel), VBQ_OK / an error otherwise.
-int launch_level_counts_hull10(const float *mu, const float *sg, int64_t n_per_ch, int64_t ch_stride, int32_t n_ch,
-                               const float *table, const double *lam, int32_t L, int vec_ok,
-                               unsigned long long *level_counts, hipStream_t st) {
-    static const bool off = [] { const char *e = getenv("VBQ_NO_HULL"); return e && e[0] == '1'; }();
-    if (off || L < 1 || L > 32) return 1;
-    HullSweep sw;
-    if (!build_hull_sweep(lam, L, sw)) return 1;
+// The grid of K1t (k_level_counts_hull) for one launch: workgroups per channel (all resident).  Pure, as quant_fast_grid.
+int64_t level_counts_hull_grid(int64_t n_per_ch, int32_t n_ch, int reserved) {
     const int64_t nquads = (n_per_ch + VBQ_HULL_NE - 1) / VBQ_HULL_NE;
     int64_t gx = (nquads + kHullThreads - 1) / kHullThreads;
     // grid = the resident workgroups, one round (measured).  With slots reserved for another stream's kernel (see
@@ -1537,8 +1540,10 @@ int launch_level_counts_hull10(const float *mu, const float *sg, int64_t n_per_c
     // EXPERIMENTS.md, "resident grids beside a collective").
     constexpr int per_cu = VBQ_HULL_WAVES * 256 / kHullThreads;
     constexpr int rounds = 1;
-    int64_t slots = resident_slots(per_cu);
-    if ((slots / n_ch) * n_ch * 10 < (int64_t)num_cus() * per_cu * 9) slots = (int64_t)num_cus() * (per_cu > 1 ? per_cu - 1 : 1);
+    int64_t slots = resident_slots(per_cu, reserved);
+    // (only with slots reserved: without a reservation the grid is floor(all / n_ch) workgroups per channel, whatever n_ch)
+    if (reserved > 0 && (slots / n_ch) * n_ch * 10 < (int64_t)num_cus() * per_cu * 9)
+        slots = (int64_t)num_cus() * (per_cu > 1 ? per_cu - 1 : 1);
     static const int exp_per_cu = [] { const char *e = getenv("VBQ_HULL_WG_PER_CU"); return e ? atoi(e) : 0; }();   // A/B switch
     if (exp_per_cu > 0 && exp_per_cu < per_cu) slots = (int64_t)num_cus() * exp_per_cu;
     int64_t cap = slots * rounds / n_ch;                    // VBQ_HULL_WAVES x 4 waves per CU resident
@@ -1555,6 +1560,20 @@ int launch_level_counts_hull10(const float *mu, const float *sg, int64_t n_per_c
         const int64_t max_iters = 65000 / ((32 / VBQ_HULL_COPIES) * (kHullThreads / 64) * VBQ_HULL_NE);
         if ((iters + gx - 1) / gx > max_iters) gx = (iters + max_iters - 1) / max_iters;
     }
+    return gx < 1 ? 1 : gx;
+}
+
+// Host side of K1t: sort the sweep, check that the bucket table applies (distinct f32 values at least one bucket
+// apart, within 16 octaves), launch.  Returns 1 when the sweep is not eligible (the caller then takes the dense
+// counting kernel), VBQ_OK / an error otherwise.
+int launch_level_counts_hull10(const float *mu, const float *sg, int64_t n_per_ch, int64_t ch_stride, int32_t n_ch,
+                               const float *table, const double *lam, int32_t L, int vec_ok,
+                               unsigned long long *level_counts, int reserved, hipStream_t st) {
+    static const bool off = [] { const char *e = getenv("VBQ_NO_HULL"); return e && e[0] == '1'; }();
+    if (off || L < 1 || L > 32) return 1;
+    HullSweep sw;
+    if (!build_hull_sweep(lam, L, sw)) return 1;
+    const int64_t gx = level_counts_hull_grid(n_per_ch, n_ch, reserved);
     static const int dbg = [] { const char *e = getenv("VBQ_FAST_DEBUG"); return e ? atoi(e) : 0; }();
     Lambdas32 l32;
     for (int i = 0; i < kMaxLambdaChunk; ++i) l32.lam[i] = i < L ? (float)lam[i] : 0.0f;
@@ -1601,7 +1620,7 @@ int launch_quant_hull_idx10(const float *mu, const float *sg, int64_t n_per_ch, 
 #define VBQ_INST_FAST(NN)                                                                                              \
     template int launch_quant_fast<NN>(const float *, const float *, int64_t, int64_t, int32_t, const float *,        \
                                        const Lambdas32 &, const float *, int32_t, uint16_t *, float *, float *, int64_t, \
-                                       int, unsigned long long *, int, hipStream_t);
+                                       int, unsigned long long *, int, int, hipStream_t);
 VBQ_FOR_EACH_N(VBQ_INST_FAST)
 #undef VBQ_INST_FAST
 #define VBQ_INST_PRUNED(NN)                                                                                           \
@@ -1612,3 +1631,25 @@ VBQ_FOR_EACH_N(VBQ_INST_PRUNED)
 
 }  // namespace vbq
 
+// The launch shape the two resident solve kernels would take: a query, nothing is launched (tests / harness output).
+extern "C" int vbq_solve_grid(int32_t kernel, int64_t n_rows, int32_t n_ch, int32_t workgroups_per_cu, int32_t reserved_workgroups,
+                              int64_t *h_grid) {
+    using namespace vbq;
+    VBQ_REQUIRE(h_grid && n_rows >= 1 && n_ch >= 1 && n_ch <= 65535, VBQ_ERR_INVALID_ARGUMENT, "vbq_solve_grid: bad sizes or null pointer");
+    VBQ_REQUIRE(kernel == VBQ_GRID_K1 || kernel == VBQ_GRID_K1T, VBQ_ERR_INVALID_ARGUMENT, "vbq_solve_grid: unknown kernel %d", kernel);
+    VBQ_REQUIRE(workgroups_per_cu >= 0 && workgroups_per_cu <= 5, VBQ_ERR_INVALID_ARGUMENT, "vbq_solve_grid: workgroups_per_cu=%d not in 0..5",
+                workgroups_per_cu);
+    const int reserved = reserved_workgroups < 0 ? default_reserved_workgroups() : reserved_workgroups;
+    if (kernel == VBQ_GRID_K1) {
+        int64_t gx = 1;
+        bool resident = false;
+        quant_fast_grid(n_rows, n_ch, workgroups_per_cu, reserved, false, &gx, &resident);
+        h_grid[0] = gx;
+        h_grid[2] = resident ? 1 : 0;
+    } else {
+        h_grid[0] = level_counts_hull_grid(n_rows, n_ch, reserved);
+        h_grid[2] = 1;
+    }
+    h_grid[1] = n_ch;
+    return VBQ_OK;
+}

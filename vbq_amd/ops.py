@@ -56,14 +56,15 @@ def quantize(mu: torch.Tensor, sigma: torch.Tensor, table_lm: torch.Tensor, lamb
              want_zhat: bool = False, want_bits: bool = False, out_idx: Optional[torch.Tensor] = None,
              out_zhat: Optional[torch.Tensor] = None, out_bits: Optional[torch.Tensor] = None,
              workspace: Optional[torch.Tensor] = None, rows: Optional[Sequence[int]] = None,
-             workgroups_per_cu: int = 0):
+             workgroups_per_cu: int = 0, reserved_workgroups: Optional[int] = None):
     """K1 (vbq_quantize_f32).  mu, sigma: f32 [rows, C] (layout 'bc') / [C, rows] ('cb') / [n] (C = 1).
     table_lm: f32 [C, T] level-major.  level_len: optional f32 [L, C, N+1].
     Returns idx u16 [L, *mu.shape] and, when asked, zhat / bits f32 of the same shape.
     layout 'bc->cb': inputs channel-last [rows, C], outputs channel-major planes [L, C, rows] (no input transposes;
     f32 mode and lambdas in the fast kernel's range only, VBQError otherwise).
     rows=(r0, r1): only that row range is solved (vbq_quantize_rows_f32; the output tensors are still full-size) --
-    the host cuts a pass into chunks to overlap K2 with K1; workgroups_per_cu: see include/vbq.h."""
+    the host cuts a pass into chunks to overlap K2 with K1; workgroups_per_cu, reserved_workgroups (slots this call's
+    resident grid leaves to a kernel of another stream; None: the library's default): see include/vbq.h."""
     to_planes = layout in ("bc->cb", LAYOUT_BC_TO_CB)
     layout = LAYOUT_BC if to_planes else _LAYOUTS[layout]
     mode = _MODES[mode]
@@ -108,7 +109,7 @@ def quantize(mu: torch.Tensor, sigma: torch.Tensor, table_lm: torch.Tensor, lamb
     if mu.numel() == 0:
         out = (idx,) + ((zhat,) if want_zhat else ()) + ((bits,) if want_bits else ())
         return out if len(out) > 1 else idx
-    if rows_range is None and not workgroups_per_cu:
+    if rows_range is None and not workgroups_per_cu and reserved_workgroups is None:
         check(h.vbq_quantize_f32(_ptr(mu), _ptr(sigma), rows, Cc, layout, _ptr(table_lm), _ptr(level_len),
                                  _doubles(lambdas), L, N, mode, _ptr(idx), _ptr(zhat), _ptr(bits), _ptr(ws), wsb,
                                  _stream(mu)), "vbq_quantize_f32")
@@ -116,7 +117,8 @@ def quantize(mu: torch.Tensor, sigma: torch.Tensor, table_lm: torch.Tensor, lamb
         r0, r1 = (0, rows) if rows_range is None else (int(rows_range[0]), int(rows_range[1]))
         check(h.vbq_quantize_rows_f32(_ptr(mu), _ptr(sigma), rows, Cc, layout, _ptr(table_lm), _ptr(level_len),
                                       _doubles(lambdas), L, N, mode, _ptr(idx), _ptr(zhat), _ptr(bits), _ptr(ws), wsb,
-                                      r0, r1, int(workgroups_per_cu), _stream(mu)), "vbq_quantize_rows_f32")
+                                      r0, r1, int(workgroups_per_cu), -1 if reserved_workgroups is None else int(reserved_workgroups),
+                                      _stream(mu)), "vbq_quantize_rows_f32")
     out = (idx,)
     if want_zhat:
         out += (zhat,)
@@ -141,7 +143,7 @@ def check_inputs(mu: torch.Tensor, sigma: torch.Tensor):
 
 def level_counts(mu: torch.Tensor, sigma: torch.Tensor, table_lm: torch.Tensor, lambdas: Sequence[float], *,
                  N: int = 10, level_len: Optional[torch.Tensor] = None, layout="bc", out: Optional[torch.Tensor] = None,
-                 workspace: Optional[torch.Tensor] = None):
+                 workspace: Optional[torch.Tensor] = None, reserved_workgroups: Optional[int] = None):
     """K1t / K1h (vbq_level_counts_f32; thresholds for raw lengths at N = 10, dense otherwise): the solve of `quantize` followed by the per-(lambda, channel) histogram of the
     winners' bit levels, in one kernel with no per-element output.  Returns int64 [L, C, N+1] (added into `out`)."""
     to_planes = layout in ("bc->cb", LAYOUT_BC_TO_CB)
@@ -175,7 +177,9 @@ def level_counts(mu: torch.Tensor, sigma: torch.Tensor, table_lm: torch.Tensor, 
         raise ValueError(f"workspace must be a device tensor of at least {wsb} bytes")
     if mu.numel():
         check(h.vbq_level_counts_f32(_ptr(mu), _ptr(sigma), rows, Cc, layout, _ptr(table_lm), _ptr(level_len),
-                                     _doubles(lambdas), L, N, _ptr(out), _ptr(ws), wsb, _stream(mu)), "vbq_level_counts_f32")
+                                     _doubles(lambdas), L, N, _ptr(out), _ptr(ws), wsb,
+                                     -1 if reserved_workgroups is None else int(reserved_workgroups), _stream(mu)),
+              "vbq_level_counts_f32")
     return out
 
 

@@ -209,7 +209,7 @@ class EntropyModelBuild:
         if self.world > 1 and counts_dtype == torch.int32:
             from .dist import CountsAllReduce
             self.reducers = [CountsAllReduce(L * C * T, self.dev, max_global_count=self.global_rows, group=group) for _ in range(2)]
-        # Launch policy beside the overlapped all-reduce (vbq_set_reserved_workgroups; EXPERIMENTS.md, "resident grids beside a
+        # Launch policy beside the overlapped all-reduce (the `reserved_workgroups` argument of the solve calls; EXPERIMENTS.md, "resident grids beside a
         # collective"): the solve kernels' resident grids assume every workgroup slot of the chip; with a collective's kernel
         # holding some of them K1 takes 1.5 x as long (Kodak-24: 346 -> 530 us with as few as 8 slots taken) against 1.25 x
         # when it leaves those slots alone or runs as short-lived workgroups -- which costs 4-5 % when nothing runs beside it.
@@ -252,30 +252,29 @@ class EntropyModelBuild:
         wsb = h.vbq_build_entropy_models_workspace_bytes(self.rows, self.C, self.L, self.N)
         ws = self._kept(("ws_build", self.L, self.C, self.rows, self.N, str(self.dev)),
                         lambda: torch.empty(max(wsb, 256), dtype=torch.uint8, device=self.dev))
-        self._set_launch_policy()
         fused = self.models is not None
         ops._lib.check(h.vbq_build_entropy_models_f32(
             ops._ptr(means_bc), ops._ptr(spread_bc), ops._spread_kind(spread), self.rows, self.C, ops._ptr(self.table),
             ops._doubles(self.lambdas), self.L, self.N, ops._ptr(self.lut1), self.lut1.numel(),
             ops._ptr(self.lut2) if fused else None, self.lut2.numel() if fused else 0, ops._ptr(self.level_counts),
             ops._ptr(self.level_len), ops._ptr(self.raw_models), ops._ptr(self.counts), int(self.counts.dtype == torch.int32),
-            ops._ptr(self.models) if fused else None, ops._ptr(ws), ws.numel(), ops._stream(means_bc)), "vbq_build_entropy_models_f32")
+            ops._ptr(self.models) if fused else None, ops._ptr(ws), ws.numel(), self._reserved(), ops._stream(means_bc)),
+            "vbq_build_entropy_models_f32")
         self._models_current = fused
         return self
 
     # ---------------------------------------------------------------- stages
-    def _set_launch_policy(self):
-        # process-wide in the library: set at the head of every pass (another build of this process may want another value)
-        ops._lib.check(ops._lib.lib().vbq_set_reserved_workgroups(self.reserved_workgroups if self.collectives else 0),
-                       "vbq_set_reserved_workgroups")
+    def _reserved(self) -> int:
+        """Workgroup slots THIS build's solve launches leave to a collective's kernel: an argument of every call (the library
+        keeps no launch state -- builds with different policies may run side by side, in threads or on several GPUs)."""
+        return self.reserved_workgroups if self.collectives else 0
 
     def pass1(self, mu_cb, sg_cb, level_len=None):
         """quantizer.py:96-105.  level_len: the table of an earlier build, if any (the reference reuses it, :166)."""
-        self._set_launch_policy()
         self.level_counts.zero_()
         self._t("k1h", 0)
         ops.level_counts(mu_cb, sg_cb, self.table, self.lambdas, N=self.N, level_len=level_len, layout="cb",
-                         out=self.level_counts, workspace=self.ws)
+                         out=self.level_counts, workspace=self.ws, reserved_workgroups=self._reserved())
         self._t("k1h", 1)
         if self.world > 1 and self.collectives:
             torch.distributed.all_reduce(self.level_counts, group=self.level_group)
@@ -303,7 +302,6 @@ class EntropyModelBuild:
             self._slot ^= 1
             self.counts = self._counts2[self._slot]
         self.wait(self._slot)                 # the all-reduce that last used this buffer
-        self._set_launch_policy()
         main = torch.cuda.current_stream(self.dev)
         self._models_current = False
         if self.side is None and self.world == 1:
@@ -312,7 +310,7 @@ class EntropyModelBuild:
             fused = self.lut2 is not None and self.models is not None
             self._t("k1", 0)
             ops.quantize(mu_cb, sg_cb, self.table, self.lambdas, N=self.N, level_len=level_len, layout="cb",
-                         out_idx=self.idx, workspace=self.ws)
+                         out_idx=self.idx, workspace=self.ws, reserved_workgroups=self._reserved())
             self._t("k1", 1)
             self._t("k2", 0)
             ops.histogram_models(self.idx, self.C, self.counts, N=self.N, lut=self.lut2 if fused else None,
@@ -324,7 +322,7 @@ class EntropyModelBuild:
         if self.side is None:
             self._t("k1", 0)
             ops.quantize(mu_cb, sg_cb, self.table, self.lambdas, N=self.N, level_len=level_len, layout="cb",
-                         out_idx=self.idx, workspace=self.ws)
+                         out_idx=self.idx, workspace=self.ws, reserved_workgroups=self._reserved())
             self._t("k1", 1)
             self._t("k2", 0)
             ops.histogram(self.idx, self.C, N=self.N, layout="cb", out=self.counts)
@@ -334,7 +332,8 @@ class EntropyModelBuild:
             for j, (r0, r1) in enumerate(self.chunks):
                 self._t("k1", 0)
                 ops.quantize(mu_cb, sg_cb, self.table, self.lambdas, N=self.N, level_len=level_len, layout="cb",
-                             out_idx=self.idx, workspace=self.ws, rows=(r0, r1), workgroups_per_cu=self.k1_workgroups_per_cu)
+                             out_idx=self.idx, workspace=self.ws, rows=(r0, r1), workgroups_per_cu=self.k1_workgroups_per_cu,
+                             reserved_workgroups=self._reserved())
                 self._t("k1", 1)
                 self._events[j].record(main)
                 with torch.cuda.stream(self.side):
