@@ -70,7 +70,7 @@ WORKLOADS = {
     "shard_1.25e8": (125_000_000, 1, "one rank's 1.25e8-element shard of the 1e9-element tensor (BASELINE.json configs[4])"),
 }
 # what the default run measures besides the headline workload (single-GPU configurations of BASELINE.json)
-OTHER_WORKLOADS = ["embeddings_1e7", "embeddings_4e5x300", "synthetic_1e8", "shard_1.25e8"]
+OTHER_WORKLOADS = ["kodak24_c32", "embeddings_1e7", "embeddings_4e5x300", "synthetic_1e8", "shard_1.25e8"]
 
 
 def make_inputs(rows, C, seed, scale_seed=1000):
@@ -307,6 +307,10 @@ def headline(full, side_file=None):
     line["rd_lagrangian_max_rel_diff_vs_oracle"] = _sig(((full.get("rd_curve") or {}).get("vs_oracle_on_sample") or {}).get("max_rel_diff"), 3)
     st = full.get("stages_ms") or {}
     line["stages_ms"] = {short: _sig(v, 4) for short, v in zip(("layout", "k1t", "k1", "k2"), st.values())} if st else None
+    # HBM fraction of every stage's kernel on ITS algorithmic bytes (K1t: 8 B / element read; K1: 8 B / element + 2 B / pair;
+    # K2: 2 B / pair read), event-timed in this run: all three recomputable from the line alone
+    line["stages_frac"] = {"k1t": _sig((full.get("roofline_k1h") or {}).get("frac"), 3), "k1": _sig(roof.get("frac"), 3),
+                           "k2": _sig((full.get("roofline_k2_histogram") or {}).get("frac"), 3)}
     if full.get("allreduce"):
         ar = full["allreduce"]
         line["allreduce"] = {"payload_bytes": ar.get("rank_histogram_payload_bytes"), "packed_3x21": ar.get("packed_3x21"),
@@ -321,7 +325,7 @@ def headline(full, side_file=None):
                                  v.get("parity_ok", v.get("parity_vs_oracle_on_sample"))] for k, v in full["workloads"].items()}
     line["full_record"] = side_file
     # never let the line outgrow the driver's parser again: shed the optional parts, largest first
-    for drop in ("workloads", "per_gpu", "allreduce", "stages_ms"):
+    for drop in ("workloads", "per_gpu", "allreduce", "stages_ms", "stages_frac"):
         if len(json.dumps(line)) < LINE_LIMIT:
             break
         line.pop(drop, None)
@@ -642,6 +646,9 @@ def run_workload(name, args, torch, dist, dev, rank, world, steps, warmup, detai
         res["per_gpu"] = gathered
 
     if not detailed:
+        if rank == 0:                     # what the CPU baseline of the line needs (no index planes: nothing to cross-check against)
+            torch.cuda.synchronize()
+            res["_host"] = (mu_h, sg_h, tab_h, build.level_len.cpu().numpy(), None)
         del build
         torch.cuda.empty_cache()
         return res if rank == 0 else None
@@ -788,6 +795,8 @@ def main():
 
     # a second communicator for the small, latency-critical all-reduce of the bit-length histogram (see pipeline.py)
     args.level_group = dist.new_group() if world > 1 else None
+    # ... and a gloo group to WAIT on without spinning (the ranks that idle while rank 0 times the CPU baseline)
+    args.cpu_group = dist.new_group(backend="gloo", timeout=__import__("datetime").timedelta(minutes=30)) if world > 1 else None
 
     if args.notebook:
         out = run_notebook(args, torch, dev, cpu=not args.no_cpu_baseline)
@@ -827,21 +836,30 @@ def main():
         if "parity" in res:
             out["parity"] = res["parity"]
             out["parity_vs_oracle_on_sample"] = res["parity_ok"]
-        if world == 1 and not args.no_cpu_baseline and host is not None:
+        if not args.no_cpu_baseline and host is not None:
+            # north_star: "next to the repo's CPU path timed on the same box's host cores in the same run" -- at EVERY N.  Rank 0
+            # runs the bounded sample on its own rows after the timed regions; with N > 1 the other ranks sleep in a socket wait
+            # meanwhile (a gloo barrier below: no spinning on the cores the sample uses).
             mu_h, sg_h, tab_h, ll_h, idx = host
             C = mu_h.shape[1]
             cb, idx_cpu, n = cpu_baseline(mu_h, sg_h, tab_h, ll_h, LAMBDAS)
+            if world > 1:
+                cb["sample"] += f"; rank 0 of {world} on its own rows, the other ranks idle"
             out["cpu_baseline"] = cb
-            # the sample doubles as a second in-run parity check of the timed configuration (pass 2)
-            got = idx[:, :, :n].permute(0, 2, 1).cpu().numpy()
-            out["parity_vs_oracle_on_sample"] = bool(out.get("parity_vs_oracle_on_sample", True) and np.array_equal(got, idx_cpu))
-            # the same formulation in NumPy, as the reference runs it (reported next to the C port, never the target)
-            out["cpu_baseline_numpy"] = cpu_baseline_numpy(mu_h, sg_h, tab_h, ll_h, LAMBDAS, idx_cpu if C > 1 else None)
+            if idx is not None:
+                # the sample doubles as a second in-run parity check of the timed configuration (pass 2)
+                got = idx[:, :, :n].permute(0, 2, 1).cpu().numpy()
+                out["parity_vs_oracle_on_sample"] = bool(out.get("parity_vs_oracle_on_sample", True) and np.array_equal(got, idx_cpu))
+            if world == 1:
+                # the same formulation in NumPy, as the reference runs it (reported next to the C port, never the target)
+                out["cpu_baseline_numpy"] = cpu_baseline_numpy(mu_h, sg_h, tab_h, ll_h, LAMBDAS, idx_cpu if C > 1 else None)
         else:
             out["cpu_baseline"] = None
         del host
     del res
     torch.cuda.empty_cache()
+    if world > 1 and not args.no_cpu_baseline:
+        dist.barrier(group=args.cpu_group)          # the other ranks wait here (blocked on a socket) while rank 0 times the CPU sample
 
     # the other BASELINE configurations, same step, same checks, fewer repetitions (every rank takes part when N > 1)
     if not args.no_other_workloads:
@@ -1142,21 +1160,85 @@ def run_api_methods(torch, dev, mu_h, sg_h, mu_bc, sg_bc, tab_h, steps=10, warmu
         "parity_vs_oracle_on_sample": bool(ok),
         "workload": f"one Kodak image [1, {H}, {W}, {C}]: ChannelwisePriorCDFQuantizer.compress_latents(means, logvars, {L} lambdas of "
                     f"post_process.py:115, return_np=False) with corrected lengths and entropy models on the device; {5 * steps} calls, one synchronisation"}
-    # the reference's own form: NumPy in, NumPy out (PCIe-bound: 3 x L x B x C x 4 B back per call) -- never the headline
+    # the reference's own form: NumPy in, NumPy out and EVERYTHING READ on the host (PCIe-bound: 3 x L x B x C x 4 B back per
+    # call) -- never the headline.  return_np=True hands out lazy views (vbq_amd.lazy): a quantity crosses PCIe when it is first read
     m_np, lv_np = m_img.cpu().numpy(), lv_img.cpu().numpy()
+    keys3 = ("Z_hat", "raw_num_bits", "num_bits")
+
+    def img_numpy(read=keys3):
+        o_ = q.compress_latents(m_np, lv_np, lams)
+        for k in read:
+            np.asarray(o_[k][lams[0]])               # first host access of the quantity: all its lambdas come over at once
+        return o_
     for _ in range(2):
-        o_np = q.compress_latents(m_np, lv_np, lams)
+        o_np = img_numpy()
     t0 = time.perf_counter()
     for _ in range(steps):
-        o_np = q.compress_latents(m_np, lv_np, lams)
+        o_np = img_numpy()
     ms_np = (time.perf_counter() - t0) / steps * 1e3
-    ok_np = all(np.array_equal(o_np[k][l], o[k][l].cpu().numpy()) for k in ("Z_hat", "raw_num_bits", "num_bits") for l in lams)
+    ok_np = all(isinstance(np.asarray(o_np[k][l]), np.ndarray) and np.array_equal(o_np[k][l], o[k][l].cpu().numpy()) for k in keys3 for l in lams)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        img_numpy(("num_bits",))
+    ms_np1 = (time.perf_counter() - t0) / steps * 1e3
+    torch.cuda.synchronize()
     out["compress_latents_image_numpy"] = {
         "ms_per_step": ms_np, "value": B * C * L / (ms_np * 1e-3), "unit": "latents/s",
         "roofline": {"bound": "pcie", "kernel": "host copies", "frac": None, "bytes_to_host_per_call": 3 * L * B * C * 4},
+        "ms_per_step_reading_num_bits_only": ms_np1,
         "parity_vs_oracle_on_sample": bool(ok and ok_np),
-        "workload": f"the same call with NumPy arrays in and out (the reference's form, return_np=True): {3 * L * B * C * 4 / 1e6:.0f} MB "
-                    "to the host per call through the pinned staging block"}
+        "workload": f"the same call with NumPy arrays in and out (the reference's form, return_np=True) and all three quantities read on "
+                    f"the host: {3 * L * B * C * 4 / 1e6:.0f} MB to the host per call through the pinned staging blocks (reading num_bits "
+                    f"alone: ms_per_step_reading_num_bits_only)"}
+    # ---- the evaluation loop's use of it (utils.py:542-554): compress(X, vae, settings) with a VAE that lives on the device, then what
+    # the loop reads -- np.sum(num_bits), np.sum(num_bits_cl) per setting and X_hat as uint8 -- without any latent-shaped array
+    # crossing PCIe: Z_hat goes to the decoder as the device tensor the kernels wrote, the sums are taken on the device in NumPy's
+    # float32 order (vbq_numpy_row_sums_f32), 2 L floats and the (stand-in) uint8 reconstructions come to the host.
+    from vbq_amd import utils as vutils
+
+    class _DeviceVAE:                                         # stand-in: the real encoder / decoder are conv nets (out of scope)
+        def encode(self, X):
+            return m_img, lv_img
+
+        def decode(self, Z):
+            return 0.5 + 0.1 * Z[..., :3]
+    vae = _DeviceVAE()
+    X = np.zeros((1, H, W, 3), np.float32)
+    seen = {}
+
+    def eval_image():
+        tmp = q.compress(X, vae, lams, clip=True)
+        seen["sums"] = vutils._sums_per_setting(tmp["num_bits"], lams)
+        seen["sums_cl"] = vutils._sums_per_setting(tmp.get("num_bits_cl", tmp["num_bits"]), lams)
+        seen["x_u8"] = vutils._reconstructions_u8(tmp["X_hat"], lams)
+        seen["tmp"] = tmp
+    for _ in range(warmup):
+        eval_image()
+    clock_ramp(torch, eval_image, min(RAMP_S, 0.15))
+    torch.cuda.synchronize()
+    before = q._stager().transfers
+    t0 = time.perf_counter()
+    for _ in range(5 * steps):
+        eval_image()
+    torch.cuda.synchronize()
+    ms_ev = (time.perf_counter() - t0) / (5 * steps) * 1e3
+    no_copies = q._stager().transfers == before
+    md_sums = np.array([np.sum(md_h[i][ch[0], wi[i]].reshape(1, H, W, C)[0]) for i in range(L)], dtype=np.float32)       # the oracle's indices
+    cl_sums = np.array([np.sum(ll_h[i][ch[0], lev[i]].reshape(1, H, W, C)[0]) for i in range(L)], dtype=np.float32)
+    z_or = np.stack([srt_h[ch[0], wi[i]] for i in range(L)]).reshape(L, H, W, C)
+    x_or = np.clip(np.round(np.clip(np.float32(0.5) + np.float32(0.1) * z_or[..., :3], 0, 1) * 255), 0, 255).astype(np.uint8)
+    ok_ev = bool(np.array_equal(seen["sums"], md_sums) and np.array_equal(seen["sums_cl"], cl_sums) and np.array_equal(seen["x_u8"], x_or)
+                 and no_copies)
+    out["evaluate_loop_image"] = {
+        "ms_per_step": ms_ev, "value": B * C * L / (ms_ev * 1e-3), "unit": "latents/s",
+        "roofline": {"bound": "hbm", "kernel": "k_prep_planes + k_quant_fast + k_gather_latents + k_np_block_sums", "achieved": alg / (ms_ev * 1e-3) / 1e9,
+                     "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": alg / (ms_ev * 1e-3) / HBM_PEAK, "algorithmic_bytes_per_launch": alg,
+                     "avg_launch_ms": ms_ev},
+        "latent_shaped_arrays_copied_to_the_host": 0 if no_copies else None, "parity_vs_oracle_on_sample": ok_ev,
+        "workload": f"one image of the evaluation loop (utils.py:542-554): quantizer.compress(X, vae, {L} lambdas, clip=True) with a VAE "
+                    f"stand-in on the device (decode gets the device Z_hat), then np.sum(num_bits) / np.sum(num_bits_cl) per lambda on the device "
+                    f"in NumPy's float32 order and X_hat as uint8: {2 * L} floats + the uint8 images reach the host; one synchronising read per "
+                    f"image; {5 * steps} images"}
     return out
 
 

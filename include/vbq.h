@@ -291,6 +291,15 @@ size_t vbq_numpy_sum_sq_workspace_bytes(int64_t n);
 int vbq_numpy_sum_sq_f32(const float *d_x, int64_t n, float *d_out, void *d_workspace, size_t workspace_bytes,
                          void *stream);
 
+/* np.sum of every row of a float32 batch [n_rows][n] in NumPy's own float32 order, bit for bit: d_out[r] = np.sum(x[r]) for a
+ * contiguous x[r] of any shape with n elements.  Replaces the reductions of the evaluation loop, utils.py:547-552
+ * (`nbits = np.sum(num_bits)`, `np.sum(num_bits_cl)` per image and lambda): with the per-lambda code lengths of
+ * vbq_compress_latents_f32 still on the device, L floats cross PCIe instead of L x [B, C] arrays.  n_rows <= 65535;
+ * workspace: vbq_numpy_row_sums_workspace_bytes(n_rows, n) bytes of device memory. */
+size_t vbq_numpy_row_sums_workspace_bytes(int64_t n_rows, int64_t n);
+int vbq_numpy_row_sums_f32(const float *d_x, int64_t n_rows, int64_t n, float *d_out, void *d_workspace,
+                           size_t workspace_bytes, void *stream);
+
 /* ----------------------------------------------------------------------------------
  * Table lookup by rank index: out[l][e] = tab[(l)][c(e)][idx[l][e]].  Replaces
  *   tf.gather(entropy_model, I, batch_dims=1)            quantizer.py:226-228

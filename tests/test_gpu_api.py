@@ -870,3 +870,102 @@ def test_compress_latents_large_batch_through_the_class():
             assert tuple(got.shape) == (4, 32, 32, C)
             assert np.array_equal(got.cpu().numpy().reshape(B, C), ref[key][l32]), (key, lamb)
     assert np.array_equal(q.entropy_models[lambs[3]], orc.entropy_models[lam32[3]])
+
+
+class TorchFakeVAE:
+    """A VAE that lives on the device: encode() returns CUDA tensors, decode() insists on getting one."""
+
+    def __init__(self, means, logvars):
+        self.means, self.logvars = torch.from_numpy(means).cuda(), torch.from_numpy(logvars).cuda()
+        self.decoded_from = None
+
+    def encode(self, X):
+        return self.means, self.logvars
+
+    def decode(self, Z):
+        assert isinstance(Z, torch.Tensor) and Z.is_cuda, "compress() must hand the decoder the device tensor"
+        self.decoded_from = Z
+        return (0.1 * Z.mean(dim=-1, keepdim=True) + 0.5).repeat_interleave(3, dim=-1)
+
+
+def test_per_image_results_stay_on_the_device_until_read(golden):
+    """compress_latents / compress (quantizer.py:190-256) with return_np=True hand out ndarray-like lazy views: nothing crosses
+    PCIe until a value is read on the host; compress() gives a torch VAE's decoder the device Z_hat (no D2H + H2D round trip);
+    the first host read of a quantity copies that quantity (and only starts the DMA of its siblings); values, dict layout and
+    pickling are those of the eager NumPy form; the evaluation loop's sums (utils.py:547-552) are taken on the device in NumPy's
+    float32 order."""
+    from vbq_amd import utils
+    from vbq_amd.lazy import LazyArray
+    g, q, orc = _case(golden)
+    lambs = list(2.0 ** np.linspace(-8, 7, 16))
+    lam32 = [np.float32(l) for l in lambs]
+    B, C = g["mu"].shape
+    q.build_entropy_models_from_latents(g["mu"], g["sigma"], lambs, 1)
+    means = g["mu"].reshape(1, 8, B // 8, C)
+    logvars = (2 * np.log(g["sigma"])).astype(np.float32).reshape(means.shape)
+    stds = (torch.exp(torch.from_numpy(logvars).cuda()) ** 0.5).cpu().numpy().reshape(B, C)
+    orc.build_entropy_models(g["mu"], g["sigma"], lam32, add_n_smoothing=1)
+    ref = orc.compress_latents(g["mu"], stds, lam32)
+    vae = TorchFakeVAE(means, logvars)
+    X = np.zeros((1, 8, B // 8, 3), np.float32)
+    stager = q._stager()
+    out = q.compress(X, vae, lambs, clip=True)
+    assert set(out) == {"Z_hat", "raw_num_bits", "num_bits_cl", "num_bits", "X_hat"} and list(out["Z_hat"]) == lambs
+    assert stager.transfers == 0 and q.entropy_models.on_device                     # nothing has crossed PCIe
+    z0 = out["Z_hat"][lambs[0]]
+    assert isinstance(z0, LazyArray) and z0.on_device and z0.shape == means.shape and z0.dtype == np.float32
+    assert vae.decoded_from.shape == (16,) + means.shape[1:] and vae.decoded_from.data_ptr() == z0.tensor.data_ptr()
+    assert out["X_hat"][lambs[3]].shape == X.shape and out["X_hat"][lambs[3]].on_device
+    # the evaluation loop's reads: sums on the device == np.sum of the host arrays, bit for bit
+    sums = utils._sums_per_setting(out["num_bits"], lambs)
+    sums_cl = utils._sums_per_setting(out["num_bits_cl"], lambs)
+    u8 = utils._reconstructions_u8(out["X_hat"], lambs)
+    assert stager.transfers == 0 and sums.dtype == np.float32 and u8.dtype == np.uint8 and u8.shape == (16,) + X.shape[1:]
+    # first host read of ONE quantity: that one (its 16 lambdas at once) + the DMA of its two siblings, not X_hat
+    nb = np.asarray(out["num_bits"][lambs[5]])
+    assert stager.transfers == 3 and not out["num_bits"][lambs[0]].on_device and out["Z_hat"][lambs[0]].on_device
+    assert out["X_hat"][lambs[0]].on_device
+    for i, (lamb, l32) in enumerate(zip(lambs, lam32)):
+        assert np.array_equal(out["num_bits"][lamb].reshape(B, C), ref["num_bits"][l32])
+        assert np.array_equal(out["Z_hat"][lamb].reshape(B, C), ref["Z_hat"][l32])
+        assert np.array_equal(out["raw_num_bits"][lamb].reshape(B, C), ref["raw_num_bits"][l32])
+        assert out["num_bits_cl"][lamb] is out["raw_num_bits"][lamb]
+        assert sums[i] == np.sum(np.asarray(out["num_bits"][lamb])[0]) and sums_cl[i] == np.sum(np.asarray(out["num_bits_cl"][lamb])[0])
+        xh = np.asarray(out["X_hat"][lamb])
+        assert xh.min() >= 0 and xh.max() <= 1 and np.array_equal(u8[i], np.clip(np.round(xh[0] * 255), 0, 255).astype(np.uint8))
+        want_x = np.clip((0.1 * ref["Z_hat"][l32].reshape(means.shape).mean(axis=-1, keepdims=True) + 0.5).repeat(3, axis=-1), 0, 1)
+        np.testing.assert_allclose(xh, want_x, rtol=1e-6)
+    assert stager.transfers == 4 and np.array_equal(nb, np.asarray(out["num_bits"][lambs[5]]))      # no second copy of anything
+    # a kept result survives later calls (the staging blocks are reused); pickles as plain arrays
+    keep = np.asarray(out["Z_hat"][lambs[2]]).copy()
+    out2 = q.compress_latents(means, logvars, lambs[:3])
+    assert np.array_equal(out2["Z_hat"][lambs[2]], keep) and np.array_equal(out["Z_hat"][lambs[2]], keep)
+    p = pickle.loads(pickle.dumps(out2))
+    assert type(p["num_bits"][lambs[1]]) is np.ndarray and np.array_equal(p["num_bits"][lambs[1]], out["num_bits"][lambs[1]])
+    # a sibling whose staging block was overwritten by a later call in the meantime is simply transferred again
+    out3 = q.compress_latents(means, logvars, lambs[4:6])
+    _ = np.asarray(out3["Z_hat"][lambs[4]])                                             # starts the DMA of out3's num_bits too
+    out4 = q.compress_latents(means, logvars, lambs[8:9])
+    _ = np.asarray(out4["num_bits"][lambs[8]])                                          # ... whose block out4 now takes
+    assert np.array_equal(out3["num_bits"][lambs[5]], out["num_bits"][lambs[5]])
+    assert np.array_equal(out3["raw_num_bits"][lambs[4]], out["raw_num_bits"][lambs[4]])
+    # NumPy VAE: the reference's own form still works (Z_hat goes through the host), same numbers
+    out_np = q.compress(X, FakeVAE(means, logvars), lambs[:2], clip=True)
+    assert isinstance(out_np["X_hat"][lambs[0]], np.ndarray)
+    np.testing.assert_allclose(out_np["X_hat"][lambs[1]], np.asarray(out["X_hat"][lambs[1]]), rtol=1e-6)
+
+
+@pytest.mark.parametrize("rows,n", [(1, 0), (3, 1), (2, 7), (16, 8191), (16, 8192), (5, 8193), (16, 12288), (3, 100_003), (16, 393_216), (2, 3_000_001)])
+def test_numpy_row_sums(rows, n):
+    """vbq_numpy_row_sums_f32 == np.sum(x[r]) bit for bit (float32, NumPy's blocks of 8192 / pairwise order), rows that start on
+    16 bytes or not."""
+    from vbq_amd import ops
+    rng = np.random.default_rng(rows * 1000 + n)
+    x = (rng.gamma(2.0, 3.0, (rows, n)) + rng.normal(0, 1e-3, (rows, n))).astype(np.float32)
+    got = ops.numpy_row_sums(torch.from_numpy(x).cuda()).cpu().numpy()
+    want = np.array([np.sum(x[r]) for r in range(rows)], dtype=np.float32)
+    assert got.dtype == np.float32 and np.array_equal(got, want)
+    if n >= 16:                                                     # a 3-D "latent" view of the same rows sums the same way
+        x3 = x[:, : (n // 8) * 8].copy().reshape(rows, 2, -1, 4)
+        got3 = ops.numpy_row_sums(torch.from_numpy(x3).cuda()).cpu().numpy()
+        assert np.array_equal(got3, np.array([np.sum(x3[r]) for r in range(rows)], dtype=np.float32))

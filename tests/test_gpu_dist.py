@@ -313,6 +313,10 @@ def _check_compact_line(line, d):
     assert line["value"] == d["value"] and line["ms_per_step"] == d["ms_per_step"] and line["n_gpus"] == d["n_gpus"]
     assert line["roofline"]["bound"] == "hbm" and 0 < line["roofline"]["frac"] < 1
     assert line["parity_vs_oracle_on_sample"] is True and len(line["per_gpu"]) == 2
+    # the N > 1 line is self-sufficient: the CPU path timed in the same run (rank 0's bounded sample), all three stage fractions
+    cb = line["cpu_baseline"]
+    assert cb is not None and cb["value"] > 0 and cb["cores"] >= 1 and cb["kind"] == "port" and "rank 0 of 2" in d["cpu_baseline"]["sample"]
+    assert set(line["stages_frac"]) == {"k1t", "k1", "k2"} and all(0 < v < 1 for v in line["stages_frac"].values())
 
 
 @pytest.mark.timeout(900)
@@ -368,3 +372,95 @@ def test_bench_two_ranks_strong_scaling_splits_one_tensor(tmp_path):
     assert d["n_gpus"] == 2 and d["scaling"] == "strong"
     assert d["config"]["elements_per_gpu"] == 18432 * 32 and d["pairs_per_step"] == 36864 * 32 * 32
     assert d["parity_vs_oracle_on_sample"] is True and d["parity"]["counts_total"] is True
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The stream-ordered HOST STAGE with world > 1: every large C = 1 configuration of BASELINE.json (1e8, 1.2e8, the 1.25e8
+# shards of the 1e9 run) has 2^24 rows per histogram row or more, so its -log2 steps cannot be tabulated and run as NumPy
+# on the HIP runtime's callback thread (pipeline.HostStage) -- beside the asynchronous, double-buffered all-reduces.
+HS_ROWS = (1 << 24) + 4096 + 7                 # global rows: just above the tabulation limit, ragged
+HS_LAMBS = [0.05, 4.0]
+
+
+def _host_stage_data():
+    from scipy.stats import norm
+    rng = np.random.default_rng(2024)
+    mu = rng.standard_normal(HS_ROWS, dtype=np.float32) * np.float32(1.23) - np.float32(0.08)
+    sg = np.exp(rng.standard_normal(HS_ROWS, dtype=np.float32) * np.float32(0.7) - np.float32(2.0))
+    xi = np.concatenate([(np.arange(2 ** n) + 0.5) / 2 ** n for n in range(N + 1)])
+    tab = norm.ppf(xi[None, :], scale=1.2329).astype(np.float32)
+    return mu, sg, tab
+
+
+def _host_stage_build(mu, sg, tab, steps, **kw):
+    from vbq_amd.pipeline import EntropyModelBuild
+    dev = torch.device("cuda", 0)
+    mu_d, sg_d = torch.from_numpy(mu).to(dev).reshape(1, -1), torch.from_numpy(sg).to(dev).reshape(1, -1)
+    b = EntropyModelBuild(mu.size, 1, HS_LAMBS, torch.from_numpy(tab).to(dev), N=N, add_n_smoothing=1, **kw)
+    assert b.has_host_stages and b.lut1 is None and b.lut2 is None, "the test must take the NumPy-on-the-callback-thread route"
+    for _ in range(steps):                        # several steps: both histogram buffers, the model table one step late
+        b.run(mu_d, sg_d)
+    models = b.finish_models()
+    b.check()
+    torch.cuda.synchronize()
+    return (b.level_counts.cpu().numpy(), b.level_len.cpu().numpy(), b.raw_models.cpu().numpy(),
+            b.counts.cpu().numpy().astype(np.int64), models.cpu().numpy())
+
+
+def _host_stage_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from vbq_amd import dist as vd
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    mu, sg, tab = _host_stage_data()
+    a, b = vd.shard_rows(HS_ROWS, rank, world)
+    res = _host_stage_build(mu[a:b], sg[a:b], tab, 3, global_rows=HS_ROWS, distributed=True, group=dist.group.WORLD,
+                            level_group=dist.new_group())
+    out.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_sharded_build_through_the_host_stage_equals_single_process():
+    """Two ranks (one device, gloo) x three steps of a C = 1 build with global_rows >= 2^24: both -log2 steps run as NumPy on the
+    HIP runtime's callback thread, stream-ordered between the kernels and beside the asynchronous all-reduces (both histogram
+    buffers in use, the model table of a step looked up one step late) -- and every rank ends with exactly the histograms,
+    length table and models one process computes from all rows, which in turn are the reference's NumPy arithmetic on the
+    oracle's counts."""
+    if not torch.cuda.is_available():
+        pytest.fail("gpu-marked test run without a ROCm device")
+    from oracle import c_oracle as CO, vbq_oracle as O
+    from vbq_amd import entropy
+    mu, sg, tab = _host_stage_data()
+    ref = _host_stage_build(mu, sg, tab, 2)
+    # the single-process build itself against the oracle: level histogram of pass 1, models = NumPy float32 ops on the counts
+    lev = O.levels_of_sorted_ranks(N)
+    n = 300_000
+    w1 = CO.quantize(mu[:n, None], sg[:n, None], tab, HS_LAMBS, N=N)
+    from vbq_amd import ops
+    lc_n = ops.level_counts(torch.from_numpy(mu[:n]).cuda(), torch.from_numpy(sg[:n]).cuda(), torch.from_numpy(tab).cuda(), HS_LAMBS, N=N)
+    assert np.array_equal(lc_n.cpu().numpy()[:, 0], np.stack([np.bincount(lev[w1[l, :, 0]], minlength=N + 1) for l in range(2)]))
+    assert int(ref[0].sum()) == 2 * HS_ROWS and int(ref[3].sum()) == 2 * HS_ROWS
+    lv = np.arange(N + 1, dtype=np.float32)
+    assert np.array_equal(ref[2], entropy.neg_log2_freq(ref[0], 1)) and np.array_equal(ref[1], (lv + ref[2]).astype(np.float32))
+    assert np.array_equal(ref[4], entropy.neg_log2_freq(ref[3], 1))
+    w2 = CO.quantize(mu[:n, None], sg[:n, None], tab, HS_LAMBS, N=N, level_len=ref[1])
+    idx_n = ops.quantize(torch.from_numpy(mu[:n]).cuda(), torch.from_numpy(sg[:n]).cuda(), torch.from_numpy(tab).cuda(), HS_LAMBS, N=N,
+                         level_len=torch.from_numpy(ref[1]).cuda())
+    assert np.array_equal(idx_n.cpu().numpy(), w2[:, :, 0])
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = 29100 + os.getpid() % 150
+    procs = [ctx.Process(target=_host_stage_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(out.get(timeout=500) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for r in range(2):
+        for got, want, what in zip(res[r], ref, ("level_counts", "level_len", "raw_models", "counts", "models")):
+            assert np.array_equal(got, want), (r, what)

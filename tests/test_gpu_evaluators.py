@@ -157,6 +157,26 @@ def test_evaluate_compression_quantizer(tmp_path):
     np.testing.assert_allclose(res["MS-SSIM (RGB)"][1], o.ms_ssim(xs, res["reconstructions"][1]), rtol=1e-12)
     out = q.compress(x[None] / 255., vae, lambs)
     assert res["B"][1, 0] == np.sum(out["num_bits"][lambs[0]])
+    for m, lamb in enumerate(lambs):                                     # the device sums ARE the reference's np.sum (utils.py:547-552)
+        nb = np.asarray(out["num_bits"][lamb])[0]
+        assert res["B"][1, m] == np.sum(nb) and res["BPL"][1, m] == np.sum(nb) / nb.size
+        assert res["BPP"][1, m] == np.sum(nb) / (H * W) and res["BPPCL"][1, m] == np.sum(np.asarray(out["num_bits_cl"][lamb])[0]) / (H * W)
+
+    # the same loop with a VAE that lives on the device: Z_hat and X_hat never visit the host as float32, same results
+    import torch
+
+    class TorchVAE(VAE):
+        def encode(self, X):
+            m, lv = VAE.encode(self, np.asarray(X))
+            return torch.from_numpy(m).cuda(), torch.from_numpy(lv).cuda()
+
+        def decode(self, Z):
+            assert Z.is_cuda
+            return 0.5 + 0.2 * Z[..., :3].repeat_interleave(4, dim=1).repeat_interleave(4, dim=2)
+    res_t = utils.evaluate_compression_quantizer(q, TorchVAE(), files, lambs, return_reconstructions=True)
+    for key in ("B", "BPP", "BPPCL", "BPL", "MSE (RGB)", "PSNR (Luma)", "MS-SSIM (Chroma)"):
+        assert np.array_equal(res_t[key], res[key]), key
+    assert all(np.array_equal(a, b) for a, b in zip(res_t["reconstructions"], res["reconstructions"]))
     with pytest.raises(Exception):
         utils.evaluate_compression_quantizer(q, vae, files, lambs, use_tf=True)
 

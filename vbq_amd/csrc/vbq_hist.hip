@@ -949,19 +949,26 @@ namespace {
 constexpr int kNpBlock = 8192;
 constexpr int kNpRunStride = 136;      // 128 + 8 words: the 64 runs of a block start on different LDS banks
 
+// SQ: sum of squares (the notebook's moment), else the plain sum (np.sum of the per-image code lengths, utils.py:547-552).
+// blockIdx.y: the row of a [rows][n] batch (row sums are independent reductions of n contiguous elements each).
+template <bool SQ>
 __global__ void __launch_bounds__(256)
-k_np_block_sums_sq(const float *__restrict__ x, float *__restrict__ block_sums) {
+k_np_block_sums(const float *__restrict__ x, long n, long nfull, float *__restrict__ block_sums, int vec) {
     __shared__ float sq[64 * kNpRunStride];
     __shared__ float racc[512];
     __shared__ float leaf[64];
-    const float *src = x + (long)blockIdx.x * kNpBlock;
+    const float *src = x + (long)blockIdx.y * n + (long)blockIdx.x * kNpBlock;
+    block_sums += (long)blockIdx.y * nfull;
     const int t = threadIdx.x;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const int e = (k * 256 + t) * 4;                      // element within the block; 4 | 128: one run per float4
-        const float4 v = *reinterpret_cast<const float4 *>(src + e);
+        float4 v;
+        if (vec) v = *reinterpret_cast<const float4 *>(src + e);
+        else v = make_float4(src[e], src[e + 1], src[e + 2], src[e + 3]);      // rows that do not start on 16 bytes
         float *d = sq + (e >> 7) * kNpRunStride + (e & 127);
-        d[0] = __fmul_rn(v.x, v.x); d[1] = __fmul_rn(v.y, v.y); d[2] = __fmul_rn(v.z, v.z); d[3] = __fmul_rn(v.w, v.w);
+        if (SQ) { d[0] = __fmul_rn(v.x, v.x); d[1] = __fmul_rn(v.y, v.y); d[2] = __fmul_rn(v.z, v.z); d[3] = __fmul_rn(v.w, v.w); }
+        else { d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w; }
     }
     __syncthreads();
 #pragma unroll
@@ -1013,10 +1020,13 @@ __device__ __noinline__ float np_pairwise(const float *a, int n) {
     return __fadd_rn(lo, np_pairwise(a + n2, n - n2));
 }
 
+template <bool SQ>
 __global__ void __launch_bounds__(256)
 k_np_finish(const float *__restrict__ x, long n, const float *__restrict__ block_sums, float *__restrict__ out) {
     __shared__ float buf[kNpBlock];
     const long nfull = n / kNpBlock;
+    x += (long)blockIdx.x * n;
+    block_sums += (long)blockIdx.x * nfull;
     float acc = 0.0f;
     for (long b0 = 0; b0 < nfull; b0 += kNpBlock) {           // the chain over the block sums, 8192 at a time out of LDS
         const int m = (int)(nfull - b0 < kNpBlock ? nfull - b0 : kNpBlock);
@@ -1030,12 +1040,26 @@ k_np_finish(const float *__restrict__ x, long n, const float *__restrict__ block
     if (tail > 0) {
         for (int i = threadIdx.x; i < tail; i += blockDim.x) {
             const float v = x[nfull * kNpBlock + i];
-            buf[i] = __fmul_rn(v, v);
+            buf[i] = SQ ? __fmul_rn(v, v) : v;
         }
         __syncthreads();
         if (threadIdx.x == 0) acc = __fadd_rn(acc, np_pairwise(buf, tail));
     }
-    if (threadIdx.x == 0) out[0] = acc;
+    if (threadIdx.x == 0) out[blockIdx.x] = acc;
+}
+
+template <bool SQ>
+int launch_np_sums(const float *d_x, int64_t n, int64_t rows, float *d_out, float *bs, hipStream_t st) {
+    const int64_t nfull = n / kNpBlock;
+    // a row of the batch starts on 16 bytes when the base does and 4 | n; otherwise 4-byte loads
+    const int vec = (reinterpret_cast<uintptr_t>(d_x) & 15) == 0 && (rows == 1 || n % 4 == 0);
+    if (nfull > 0) {
+        hipLaunchKernelGGL((k_np_block_sums<SQ>), dim3((unsigned)nfull, (unsigned)rows), dim3(256), 0, st, d_x, (long)n, (long)nfull, bs, vec);
+        VBQ_CHECK_LAUNCH("np_block_sums");
+    }
+    hipLaunchKernelGGL((k_np_finish<SQ>), dim3((unsigned)rows), dim3(256), 0, st, d_x, (long)n, bs, d_out);
+    VBQ_CHECK_LAUNCH("np_finish");
+    return VBQ_OK;
 }
 }  // namespace
 }  // namespace vbq
@@ -1054,17 +1078,26 @@ extern "C" int vbq_numpy_sum_sq_f32(const float *d_x, int64_t n, float *d_out, v
     const size_t need = vbq_numpy_sum_sq_workspace_bytes(n);
     VBQ_REQUIRE(n == 0 || (d_workspace && workspace_bytes >= need), VBQ_ERR_WORKSPACE,
                 "vbq_numpy_sum_sq_f32: workspace of %zu bytes given, %zu needed", workspace_bytes, need);
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const int64_t nfull = n / kNpBlock;
-    VBQ_REQUIRE(nfull <= 0x7fffffffLL, VBQ_ERR_UNSUPPORTED, "vbq_numpy_sum_sq_f32: more than 2^44 elements");
-    float *bs = reinterpret_cast<float *>(d_workspace);
-    if (nfull > 0) {
-        hipLaunchKernelGGL(k_np_block_sums_sq, dim3((unsigned)nfull), dim3(256), 0, st, d_x, bs);
-        VBQ_CHECK_LAUNCH("np_block_sums");
-    }
-    hipLaunchKernelGGL(k_np_finish, dim3(1), dim3(256), 0, st, d_x, (long)n, bs, d_out);
-    VBQ_CHECK_LAUNCH("np_finish");
-    return VBQ_OK;
+    VBQ_REQUIRE(n / kNpBlock <= 0x7fffffffLL, VBQ_ERR_UNSUPPORTED, "vbq_numpy_sum_sq_f32: more than 2^44 elements");
+    return launch_np_sums<true>(d_x, n, 1, d_out, reinterpret_cast<float *>(d_workspace), reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" size_t vbq_numpy_row_sums_workspace_bytes(int64_t n_rows, int64_t n) {
+    return n_rows <= 0 || n <= 0 ? 0 : (size_t)n_rows * (size_t)(n / vbq::kNpBlock + 1) * sizeof(float);
+}
+
+extern "C" int vbq_numpy_row_sums_f32(const float *d_x, int64_t n_rows, int64_t n, float *d_out, void *d_workspace,
+                                      size_t workspace_bytes, void *stream) {
+    using namespace vbq;
+    VBQ_REQUIRE(n_rows >= 0 && n >= 0 && n_rows <= 65535, VBQ_ERR_INVALID_ARGUMENT, "vbq_numpy_row_sums_f32: bad sizes (at most 65535 rows)");
+    if (n_rows == 0) return VBQ_OK;
+    VBQ_REQUIRE(d_out && (n == 0 || d_x), VBQ_ERR_INVALID_ARGUMENT, "vbq_numpy_row_sums_f32: null pointer");
+    VBQ_REQUIRE((reinterpret_cast<uintptr_t>(d_x) & 3) == 0, VBQ_ERR_INVALID_ARGUMENT, "vbq_numpy_row_sums_f32: d_x must be 4-byte aligned");
+    const size_t need = vbq_numpy_row_sums_workspace_bytes(n_rows, n);
+    VBQ_REQUIRE(n == 0 || (d_workspace && workspace_bytes >= need), VBQ_ERR_WORKSPACE,
+                "vbq_numpy_row_sums_f32: workspace of %zu bytes given, %zu needed", workspace_bytes, need);
+    VBQ_REQUIRE(n / kNpBlock <= 0x7fffffffLL, VBQ_ERR_UNSUPPORTED, "vbq_numpy_row_sums_f32: more than 2^44 elements per row");
+    return launch_np_sums<false>(d_x, n, n_rows, d_out, reinterpret_cast<float *>(d_workspace), reinterpret_cast<hipStream_t>(stream));
 }
 
 extern "C" int vbq_moments_f32(const float *d_x, int64_t n_rows, int32_t n_ch, int32_t layout, double *d_out,

@@ -1,0 +1,271 @@
+"""Per-image results that stay on the device until somebody reads them on the host.
+
+`ChannelwisePriorCDFQuantizer.compress_latents` / `.compress` (img-compression/quantizer.py:190-256) return, per quantity
+('Z_hat', 'raw_num_bits', 'num_bits', 'X_hat') and lambda, an array shaped like the latents.  The reference's arrays are NumPy
+(its np.reshape moves everything to the host, :237): 75 MB per Kodak image x 16 lambdas, 2.7 ms over PCIe against 0.09 ms for the
+kernels -- although the caller of the evaluation loop (utils.py:542-554) only wants L sums of 'num_bits' and hands 'Z_hat'
+straight back to the decoder.  So `return_np=True` returns `LazyArray`s: ndarray-like views (shape, dtype, indexing, arithmetic,
+np.* functions, pickling as the ndarray they stand for) over the device tensors the kernels wrote.  Nothing crosses PCIe until
+a value is read on the host; consumers that know about the device (`compress` with a torch VAE, `vbq_amd.utils.evaluate_*`)
+take `.tensor` and never trigger a copy.
+
+First host access of a quantity copies THAT quantity of the call -- all its lambdas at once -- through a persistent pinned
+staging block, in three pieces whose transfers overlap the copies out of the block (NumPy releases the GIL for large copies:
+the pieces are copied out by a small thread pool), and starts the DMA of the call's other quantities into their staging
+blocks in the background (no host time): reading everything costs what the eager form cost, reading one quantity a third of
+it, reading nothing nothing.  Not thread-safe (one evaluation loop per quantizer object), like the staging blocks before.
+"""
+from __future__ import annotations
+
+import itertools
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+from numpy.lib.mixins import NDArrayOperatorsMixin
+
+_PIECES = 3
+_THREADED_FROM = 1 << 22           # bytes: below this one plain copy is faster than waking the pool
+_ids = itertools.count(1)
+
+
+class HostStager:
+    """The persistent pinned staging blocks of one quantizer (one per quantity name, grown on demand) and the small thread
+    pool that copies results out of them into ordinary pageable arrays -- so that a result kept for later does not pin
+    page-locked memory (an evaluation loop over a data set would otherwise accumulate GBs of it)."""
+
+    def __init__(self):
+        self.blocks: Dict[str, torch.Tensor] = {}
+        self.owner: Dict[str, int] = {}          # id of the DeviceStack whose data the block holds / is receiving
+        self.events: Dict[str, list] = {}
+        self._pool = None
+        self.transfers = 0                       # device-to-host copies issued (tests read it)
+        self.bytes = 0
+
+    def pool(self):
+        if self._pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool = ThreadPoolExecutor(max_workers=_PIECES)
+        return self._pool
+
+    @staticmethod
+    def _cuts(n0: int):
+        k = min(_PIECES, max(1, n0))
+        return [(n0 * j) // k for j in range(k + 1)]
+
+    def issue(self, stack: "DeviceStack"):
+        """Asynchronous device -> staging copies of `stack` (pieces along its first axis, one event each)."""
+        t = stack.tensor
+        if self.owner.get(stack.name) == stack.id:
+            return
+        h = self.blocks.get(stack.name)
+        if h is None or h.numel() < t.numel() or h.dtype != t.dtype:
+            h = self.blocks[stack.name] = torch.empty(max(t.numel(), 1), dtype=t.dtype, pin_memory=True)
+        st = torch.cuda.current_stream(t.device)
+        if stack.ready is not None:
+            st.wait_event(stack.ready)           # the kernels that produce it may have been enqueued on another stream
+        hv = h[:t.numel()].view(t.shape)
+        evs = []
+        cuts = self._cuts(t.shape[0]) if t.dim() else [0, 1]
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            if t.dim():
+                hv[a:b].copy_(t[a:b], non_blocking=True)
+            else:
+                hv.copy_(t, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(st)
+            evs.append(ev)
+        self.owner[stack.name] = stack.id
+        self.events[stack.name] = evs
+        self.transfers += 1
+        self.bytes += t.numel() * t.element_size()
+
+    def fetch(self, stack: "DeviceStack") -> np.ndarray:
+        """The host copy of `stack` (a fresh pageable array), its siblings' transfers started on the way."""
+        self.issue(stack)
+        for sib in stack.siblings:
+            if sib is not stack and sib._host is None:
+                self.issue(sib)
+        t = stack.tensor
+        h = self.blocks[stack.name][:t.numel()].view(t.shape).numpy()
+        evs = self.events[stack.name]
+        out = np.empty(t.shape, dtype=h.dtype)
+        if t.dim() == 0 or t.numel() == 0:
+            evs[-1].synchronize()
+            out[...] = h
+            return out
+        cuts = self._cuts(t.shape[0])
+
+        def piece(j):
+            evs[j].synchronize()
+            np.copyto(out[cuts[j]:cuts[j + 1]], h[cuts[j]:cuts[j + 1]])
+        if t.numel() * t.element_size() >= _THREADED_FROM and len(evs) > 1:
+            list(self.pool().map(piece, range(len(evs))))
+        else:
+            for j in range(len(evs)):
+                piece(j)
+        return out
+
+
+class DeviceStack:
+    """One quantity of one call: a device tensor [L, *shape] and, once somebody has read it, its host copy."""
+
+    def __init__(self, name: str, tensor: torch.Tensor, stager: Optional[HostStager], record_ready: bool = True):
+        self.name, self.tensor, self.stager = name, tensor, stager
+        self.id = next(_ids)
+        self.siblings = [self]
+        self._host = None
+        self.ready = None
+        if record_ready and tensor.is_cuda:
+            self.ready = torch.cuda.Event()
+            self.ready.record(torch.cuda.current_stream(tensor.device))
+
+    @property
+    def on_device(self) -> bool:
+        """True while no host copy has been made."""
+        return self._host is None
+
+    def host(self) -> np.ndarray:
+        if self._host is None:
+            if not self.tensor.is_cuda or self.stager is None:
+                self._host = self.tensor.detach().cpu().numpy()
+            else:
+                self._host = self.stager.fetch(self)
+        return self._host
+
+    def rows(self):
+        return [LazyArray(self, i) for i in range(self.tensor.shape[0])]
+
+
+def group(stacks):
+    """Quantities of ONE call: the first host access of any of them starts the transfers of the others as well."""
+    stacks = [s for s in stacks if s is not None]
+    for s in stacks:
+        s.siblings = stacks
+    return stacks
+
+
+class LazyArray(NDArrayOperatorsMixin):
+    """Row `i` of a DeviceStack, behaving like the NumPy array it stands for.  `.tensor`: the device tensor (no copy);
+    everything else goes through `__array__`, which makes the stack's host copy on first use."""
+    __slots__ = ("_stack", "_i")
+    __array_priority__ = 100.0
+
+    def __init__(self, stack: DeviceStack, i: int):
+        self._stack, self._i = stack, i
+
+    # ---- what is known without touching the data
+    @property
+    def tensor(self) -> torch.Tensor:
+        return self._stack.tensor[self._i]
+
+    @property
+    def on_device(self) -> bool:
+        return self._stack.on_device
+
+    @property
+    def shape(self):
+        return tuple(self._stack.tensor.shape[1:])
+
+    @property
+    def ndim(self):
+        return self._stack.tensor.dim() - 1
+
+    @property
+    def size(self):
+        return int(np.prod(self.shape, dtype=np.int64))
+
+    @property
+    def dtype(self):
+        return _NP_DTYPES[self._stack.tensor.dtype]
+
+    @property
+    def nbytes(self):
+        return self.size * self.dtype.itemsize
+
+    def __len__(self):
+        if not self.shape:
+            raise TypeError("len() of unsized object")
+        return self.shape[0]
+
+    # ---- the data
+    def __array__(self, dtype=None, copy=None):
+        a = self._stack.host()[self._i, ...]             # (the Ellipsis keeps a 0-d row an array, a view as well)
+        if dtype is not None and np.dtype(dtype) != a.dtype:
+            return a.astype(dtype)
+        return a.copy() if copy else a
+
+    def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
+        conv = lambda x: np.asarray(x) if isinstance(x, LazyArray) else x
+        inputs = tuple(conv(x) for x in inputs)
+        if "out" in kwargs:
+            kwargs["out"] = tuple(conv(x) for x in kwargs["out"])
+        return getattr(ufunc, method)(*inputs, **kwargs)
+
+    def __getitem__(self, key):
+        return np.asarray(self)[key]
+
+    def __setitem__(self, key, value):
+        np.asarray(self)[key] = value
+
+    def __iter__(self):
+        return iter(np.asarray(self))
+
+    def __getattr__(self, name):                 # .sum(), .reshape(), .astype(), .T, ...: the ndarray's own
+        if name.startswith("__") and name.endswith("__"):
+            raise AttributeError(name)
+        return getattr(np.asarray(self), name)
+
+    def __bool__(self):
+        return bool(np.asarray(self))
+
+    def __float__(self):
+        return float(np.asarray(self))
+
+    def __int__(self):
+        return int(np.asarray(self))
+
+    def __index__(self):
+        return np.asarray(self).__index__()
+
+    def __reduce__(self):                        # pickles as the ndarray it stands for
+        return np.asarray(self).__reduce__()
+
+    def __copy__(self):
+        return np.asarray(self).copy()
+
+    def __deepcopy__(self, memo):
+        return np.asarray(self).copy()
+
+    def __repr__(self):
+        where = "on the device" if self.on_device else "host copy made"
+        return f"LazyArray(shape={self.shape}, dtype={self.dtype}, {where})"
+
+
+_NP_DTYPES = {torch.float32: np.dtype(np.float32), torch.float64: np.dtype(np.float64), torch.int32: np.dtype(np.int32),
+              torch.int64: np.dtype(np.int64), torch.uint16: np.dtype(np.uint16), torch.uint8: np.dtype(np.uint8),
+              torch.int16: np.dtype(np.int16), torch.float16: np.dtype(np.float16), torch.bool: np.dtype(np.bool_)}
+
+
+def device_tensor(x) -> Optional[torch.Tensor]:
+    """The device tensor behind `x` when it is a LazyArray (or already a device tensor), else None."""
+    if isinstance(x, LazyArray):
+        return x.tensor
+    if isinstance(x, torch.Tensor) and x.is_cuda:
+        return x
+    return None
+
+
+def common_stack(values) -> Optional[torch.Tensor]:
+    """When `values` are the LazyArrays 0, 1, 2, ... of ONE DeviceStack, in order: that stack's device tensor [L, ...] (a
+    consumer can then work on all lambdas at once); else None."""
+    values = list(values)
+    if not values or not all(isinstance(v, LazyArray) for v in values):
+        return None
+    st = values[0]._stack
+    if any(v._stack is not st for v in values):
+        return None
+    idx = [v._i for v in values]
+    if idx == list(range(st.tensor.shape[0])):
+        return st.tensor
+    return st.tensor[idx]

@@ -314,6 +314,22 @@ def numpy_sum_sq(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def numpy_row_sums(x: torch.Tensor, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """vbq_numpy_row_sums_f32: np.sum(x[r]) for every r of a contiguous float32 device tensor [rows, ...], in NumPy's own float32
+    summation order (bit for bit) -> f32 [rows] on the device.  The reductions of the evaluation loop (utils.py:547-552) without
+    bringing the per-lambda arrays to the host."""
+    x = _dev(x, torch.float32, "x")
+    rows = x.shape[0]
+    n = x[0].numel() if rows else 0
+    out = torch.empty(rows, dtype=torch.float32, device=x.device)
+    h = _lib.lib()
+    wsb = h.vbq_numpy_row_sums_workspace_bytes(rows, n)
+    ws = workspace if workspace is not None and workspace.numel() * workspace.element_size() >= wsb else \
+        torch.empty(max(wsb, 4), dtype=torch.uint8, device=x.device)
+    check(h.vbq_numpy_row_sums_f32(_ptr(x), rows, n, _ptr(out), _ptr(ws), wsb, _stream(x)), "vbq_numpy_row_sums_f32")
+    return out
+
+
 def gather(idx: torch.Tensor, tab: torch.Tensor, n_ch: int, *, N: int = 10, layout="bc", out_layout=None):
     """vbq_gather_f32: out[l][e] = tab[(l,) c(e), idx[l][e]].  tab: f32 [C, T] or [L, C, T] indexed by RANK.
     With out_layout != layout the result comes back transposed (e.g. idx [L, C, B] -> out [L, B, C])."""

@@ -81,6 +81,9 @@ class DeviceModels(MutableMapping):
             h = self._stack.cpu().numpy()
             h.setflags(write=False)
             self._host = h
+            # ONE view object per key, made once: callers that key caches on the arrays' identities (_keyed_dev) see the same
+            # object on every read instead of a fresh view per __getitem__ (which re-uploaded the whole table per image)
+            self._rows = [h[i] for i in range(h.shape[0])]
         return self._host
 
     def __getitem__(self, k):
@@ -89,7 +92,8 @@ class DeviceModels(MutableMapping):
         if k in self._gone:
             raise KeyError(k)
         i = self._index[k]                   # KeyError as a dict
-        return self._materialise()[i]
+        self._materialise()
+        return self._rows[i]
 
     def __setitem__(self, k, v):
         self._over[k] = v
@@ -360,6 +364,14 @@ class ChannelwisePriorCDFQuantizer:
             self._dev_cache[name] = ws
         return ws
 
+    def _stager(self):
+        """The pinned staging blocks behind the lazy per-image results (vbq_amd.lazy.HostStager), one set per quantizer."""
+        st = self._dev_cache.get("_stager")
+        if st is None:
+            from .lazy import HostStager
+            st = self._dev_cache["_stager"] = HostStager()
+        return st
+
     def _latents_call(self, means_bc, spread_bc, lambs, *, spread, level_len, models):
         """vbq_compress_latents_f32: planes, solve and the fused lookups of one batch in ONE C call (three launches).
         -> (Z_hat, raw_num_bits, num_bits | None), channel-last [L, B, C] device tensors."""
@@ -532,34 +544,15 @@ class ChannelwisePriorCDFQuantizer:
             arrs = {"Z_hat": zhat.reshape((L,) + shape), "raw_num_bits": raw_bits.reshape((L,) + shape),
                     "num_bits": num_bits.reshape((L,) + shape)}
         else:
-            # Device -> host through ONE persistent pinned staging block per quantity (grown on demand, reused by every
-            # call) and one asynchronous copy each; the caller gets ordinary pageable arrays copied out of it, so a result
-            # kept for later does not pin L times its own size of page-locked memory (an evaluation loop over a whole
-            # data set would otherwise accumulate GBs of it).
-            stage = self._dev_cache.setdefault("_pinned_stage", {})
-            host, done = {}, {}
-            st = torch.cuda.current_stream(self.device)
-            for key, t in (("Z_hat", zhat), ("raw_num_bits", raw_bits), ("num_bits", num_bits)):
-                h = stage.get(key)
-                if h is None or h.numel() < t.numel() or h.dtype != t.dtype:
-                    h = torch.empty(t.numel(), dtype=t.dtype, pin_memory=True)
-                    stage[key] = h
-                h[:t.numel()].view(t.shape).copy_(t, non_blocking=True)
-                host[key] = h[:t.numel()].view(t.shape)
-                done[key] = torch.cuda.Event()
-                done[key].record(st)
-
-            def copy_out(key):               # the copy out of the staging block of one quantity overlaps the next one's transfer
-                done[key].synchronize()
-                return np.array(host[key].numpy().reshape((L,) + shape))     # [L, B, C] -> L x latent shape (:237)
-            if zhat.numel() * 4 >= (1 << 22):    # NumPy releases the GIL for large copies: the three run side by side
-                from concurrent.futures import ThreadPoolExecutor
-                pool = self._dev_cache.get("_copy_pool")
-                if pool is None:
-                    pool = self._dev_cache["_copy_pool"] = ThreadPoolExecutor(max_workers=3)
-                arrs = dict(zip(host, pool.map(copy_out, list(host))))
-            else:
-                arrs = {key: copy_out(key) for key in host}
+            # NumPy-like views over the device tensors (vbq_amd.lazy): a quantity crosses PCIe -- through a persistent pinned
+            # staging block, all its lambdas at once -- when somebody first READS it on the host; a caller that hands Z_hat back
+            # to a decoder on the device and sums num_bits there (compress / vbq_amd.utils.evaluate_*) copies nothing.
+            from .lazy import DeviceStack, group
+            stager = self._stager()
+            stacks = group([DeviceStack("Z_hat", zhat.reshape((L,) + shape), stager),
+                            DeviceStack("raw_num_bits", raw_bits.reshape((L,) + shape), stager),
+                            DeviceStack("num_bits", num_bits.reshape((L,) + shape), stager)])
+            arrs = {st.name: st.rows() for st in stacks}
         has_cl = bool(self.raw_code_length_entropy_models)
         for i, lamb in enumerate(lambs):
             output["Z_hat"][lamb] = arrs["Z_hat"][i]
@@ -604,16 +597,34 @@ class ChannelwisePriorCDFQuantizer:
         return {lamb: (zhat[i].cpu().numpy() if return_np else zhat[i]) for i, lamb in enumerate(lambs)}
 
     def compress(self, X, vae, lambs, clip=True):
+        """quantizer.py:242-256.  With a torch VAE on the device nothing crosses PCIe here: the decoder gets the Z_hat tensor the
+        kernels wrote (the reference -- and this method before round 5 -- went through NumPy: a device-to-host copy of L latent
+        tensors and the same bytes back for `vae.decode`), and 'X_hat' comes back as lazy views like the other quantities."""
+        from .lazy import DeviceStack, common_stack
         lambs = list(lambs)
+        L = len(lambs)
         posterior_means, posterior_logvars = vae.encode(X)
         output = self.compress_latents(posterior_means, posterior_logvars, lambs)
         Z_hat_dict = output["Z_hat"]
-        Z_hat_batch = np.stack([Z_hat_dict[lamb] for lamb in lambs])                 # len(lambs) x latent shape
         latent_shape = tuple(np.shape(posterior_means))
-        Z_flat = Z_hat_batch.reshape((-1,) + latent_shape[1:])
-        if isinstance(posterior_means, torch.Tensor):
-            Z_flat = torch.from_numpy(Z_flat).to(posterior_means.device)
-        X_hat_batch = _to_numpy(vae.decode(Z_flat)).reshape((len(lambs),) + tuple(np.shape(X)))
+        z_dev = common_stack([Z_hat_dict[lamb] for lamb in lambs]) if isinstance(posterior_means, torch.Tensor) else None
+        if z_dev is not None:
+            Z_flat = z_dev.reshape((-1,) + latent_shape[1:])                          # len(lambs) * batch x latent shape[1:]
+            if Z_flat.device != posterior_means.device:
+                Z_flat = Z_flat.to(posterior_means.device)
+        else:
+            Z_hat_batch = np.stack([Z_hat_dict[lamb] for lamb in lambs])             # len(lambs) x latent shape
+            Z_flat = Z_hat_batch.reshape((-1,) + latent_shape[1:])
+            if isinstance(posterior_means, torch.Tensor):
+                Z_flat = torch.from_numpy(Z_flat).to(posterior_means.device)
+        X_hat = vae.decode(Z_flat)
+        if isinstance(X_hat, torch.Tensor) and X_hat.is_cuda:
+            X_hat_batch = X_hat.detach().reshape((L,) + tuple(np.shape(X)))
+            if clip:
+                X_hat_batch = X_hat_batch.clamp(0, 1)                                  # np.clip(X_hat_batch, 0, 1), :253
+            output["X_hat"] = dict(zip(lambs, DeviceStack("X_hat", X_hat_batch.contiguous(), self._stager()).rows()))
+            return output
+        X_hat_batch = _to_numpy(X_hat).reshape((L,) + tuple(np.shape(X)))
         if clip:
             X_hat_batch = np.clip(X_hat_batch, 0, 1)
         output["X_hat"] = {lamb: X_hat_batch[i] for i, lamb in enumerate(lambs)}

@@ -193,6 +193,31 @@ def evaluate_compression_jpg(img_file, quality=(1, 10), return_reconstructions=F
     return results
 
 
+def _sums_per_setting(d, settings):
+    """[np.sum(np.asarray(d[lamb])[0]) for lamb in settings] (utils.py:547-552) as float32 scalars: on the device, in NumPy's
+    own summation order, while the arrays are device-resident float32 views of one call with a batch of one image; on the host
+    otherwise."""
+    from . import ops
+    from .lazy import common_stack
+    vals = [d[lamb] for lamb in settings]
+    t = common_stack(vals)
+    if t is not None and t.dtype == torch.float32 and t.dim() >= 2 and t.shape[1] == 1 and t.is_contiguous():
+        return ops.numpy_row_sums(t).cpu().numpy()
+    return np.array([np.sum(np.asarray(v)[0]) for v in vals])
+
+
+def _reconstructions_u8(d, settings):
+    """np.clip(np.round(X_hat * 255), 0, 255).astype(np.uint8) of the first image of every setting (utils.py:554-556) ->
+    [M, H, W, 3] uint8 on the host; taken on the device when the reconstructions still live there (a quarter of the bytes
+    cross PCIe)."""
+    from .lazy import common_stack
+    vals = [d[lamb] for lamb in settings]
+    t = common_stack(vals)
+    if t is not None and t.dtype == torch.float32:
+        return (t[:, 0] * 255).round().clamp(0, 255).to(torch.uint8).cpu().numpy()
+    return np.stack([np.clip(np.round(np.asarray(v)[0] * 255), 0, 255).astype(np.uint8) for v in vals])
+
+
 def evaluate_compression_quantizer(quantizer, vae, test_img_files, settings, model_input_float_type="float32",
                                    return_reconstructions=False, use_tf=False):
     """utils.py:502-634: compress every image with `quantizer.compress(X, vae, settings, clip=True)` and report bits
@@ -217,17 +242,21 @@ def evaluate_compression_quantizer(quantizer, vae, test_img_files, settings, mod
         x = np.asarray(img)
         X = (x / 255.)[None, ...].astype(model_input_float_type)
         tmp = quantizer.compress(X, vae, settings, clip=True)
+        num_bits_cl = tmp.get("num_bits_cl", tmp["num_bits"])
+        # utils.py:547-552: nbits = np.sum(num_bits), np.sum(num_bits_cl) per setting.  While the per-lambda arrays are still on
+        # the device (vbq_amd.lazy) the sums are taken there, in NumPy's own float32 order (vbq_numpy_row_sums_f32), and M floats
+        # come to the host instead of M latent-shaped arrays; otherwise np.sum as in the reference.
+        sums = _sums_per_setting(tmp["num_bits"], settings)
+        sums_cl = _sums_per_setting(num_bits_cl, settings)
+        x_hat_u8 = _reconstructions_u8(tmp["X_hat"], settings)                       # [M, H, W, 3] uint8 (host)
         img_hats, x_hats = [], []
         for m, lamb in enumerate(settings):
-            num_bits = np.asarray(tmp["num_bits"][lamb])[0]
-            nbits = np.sum(num_bits)
+            nbits = sums[m]
             results["B"][n, m] = nbits
             results["BPP"][n, m] = nbits / num_pixels
-            results["BPL"][n, m] = nbits / num_bits.size
-            num_bits_cl = tmp.get("num_bits_cl", tmp["num_bits"])
-            results["BPPCL"][n, m] = np.sum(np.asarray(num_bits_cl[lamb])[0]) / num_pixels
-            X_hat = np.asarray(tmp["X_hat"][lamb])[0]
-            x_hat = np.clip(np.round(X_hat * 255), 0, 255).astype(np.uint8)
+            results["BPL"][n, m] = nbits / (tmp["num_bits"][lamb].size // len(tmp["num_bits"][lamb]))
+            results["BPPCL"][n, m] = sums_cl[m] / num_pixels
+            x_hat = x_hat_u8[m]
             img_hats.append(Image.fromarray(x_hat))
             x_hats.append(x_hat)
         x_yc = np.asarray(img.convert("YCbCr"))
