@@ -819,6 +819,55 @@ def test_quantize_facade_planes_out_and_in_place_table_edit():
     tab2[3, 5] = 1e9
     with pytest.raises(ValueError):
         vbq_amd.quantize(mu, sg, 1.0, table=tab2)
+    # ... the same guarantee without xxhash (np.array_equal against the kept copy; never a cryptographic hash of 2 MB per call)
+    from vbq_amd import api
+    import hashlib
+    real_xxh3, real_blake = api._xxh3, hashlib.blake2b
+    try:
+        api._xxh3 = lambda: None
+        hashlib.blake2b = None                                 # any use would raise TypeError
+        api._CHECKED.clear()
+        tab3 = tab.copy()
+        a = vbq_amd.quantize(mu, sg, 1.0, table=tab3)
+        assert np.array_equal(vbq_amd.quantize(mu, sg, 1.0, table=tab3), a) and len(api._CHECKED) == 1
+        tab3[:] = vbq_amd.gaussian_table(0.6 * s_c, N)
+        b = vbq_amd.quantize(mu, sg, 1.0, table=tab3)
+        assert np.array_equal(b, CO.quantize(mu, sg, tab3, [1.0], N=N)[0]) and not np.array_equal(a, b)
+    finally:
+        api._xxh3, hashlib.blake2b = real_xxh3, real_blake
+    # a READ-ONLY array that is the very object prepared before cannot have changed: no pass over its content on later calls ...
+    api._CHECKED.clear()
+    tab4 = tab.copy()
+    tab4.setflags(write=False)
+    c0 = vbq_amd.quantize(mu, sg, lam[3], table=tab4)
+    real_same = api._NumpyEntry.same_content
+    try:
+        api._NumpyEntry.same_content = lambda self, arr: (_ for _ in ()).throw(AssertionError("content check on an immutable table"))
+        assert np.array_equal(vbq_amd.quantize(mu, sg, lam[3], table=tab4, validate=False), c0)
+        assert np.array_equal(vbq_amd.quantize(mu, sg, lam[3], table=tab4), wi[3])
+    finally:
+        api._NumpyEntry.same_content = real_same
+    # ... but once it is writeable again it is compared again (and a read-only VIEW of a writeable array never took that path)
+    tab4.setflags(write=True)
+    tab4[:] = vbq_amd.gaussian_table(1.3 * s_c, N)
+    assert np.array_equal(vbq_amd.quantize(mu, sg, lam[3], table=tab4), CO.quantize(mu, sg, tab4, [lam[3]], N=N)[0])
+    base = tab.copy()
+    view = base[:]
+    view.setflags(write=False)
+    v0 = vbq_amd.quantize(mu, sg, lam[3], table=view)
+    base[:] = vbq_amd.gaussian_table(2.1 * s_c, N)
+    v1 = vbq_amd.quantize(mu, sg, lam[3], table=view)
+    assert np.array_equal(v0, wi[3]) and np.array_equal(v1, CO.quantize(mu, sg, base, [lam[3]], N=N)[0]) and not np.array_equal(v0, v1)
+    # validate=False is cached as well, and a later validate=True still checks
+    api._CHECKED.clear()
+    bad = tab.copy()
+    bad[3, 5] = 1e9
+    vbq_amd.quantize(mu, sg, 1.0, table=bad, validate=False)
+    assert len(api._CHECKED) == 1
+    vbq_amd.quantize(mu, sg, 1.0, table=bad, validate=False)
+    assert len(api._CHECKED) == 1
+    with pytest.raises(ValueError):
+        vbq_amd.quantize(mu, sg, 1.0, table=bad)
 
 
 @pytest.mark.timeout(600)

@@ -44,6 +44,22 @@ def main():
     print(f"ops.quantize L=32, out given      {per_call(lambda: ops.quantize(mu, sg, tab, LAMBDAS, N=N_BITS, layout='cb', out_idx=idx32)):7.1f} us per call")
     print(f"vbq_amd.quantize facade L=1 (bc)  {per_call(lambda: vbq_amd.quantize(mu_bc, sg_bc, lam1, table=tab)):7.1f} us per call")
     print(f"vbq_amd.quantize facade L=32 (bc) {per_call(lambda: vbq_amd.quantize(mu_bc, sg_bc, LAMBDAS, table=tab)):7.1f} us per call")
+    # NumPy tables (api._device_table): a writeable array is compared with what was uploaded on EVERY call (xxh3 when xxhash is
+    # importable, np.array_equal against a kept copy otherwise -- the second block hides xxhash to show that route); a read-only
+    # array that is the very object prepared before takes the identity path
+    import vbq_amd.api as api
+    tab_w = tab_h.copy()
+    tab_ro = tab_h.copy()
+    tab_ro.setflags(write=False)
+    for hide in (False, True):
+        real = api._xxh3
+        if hide:
+            api._xxh3 = lambda: None
+        api._CHECKED.clear()
+        tag = "no xxhash" if hide else ("xxhash" if real() is not None else "no xxhash")
+        print(f"facade L=1, NumPy [256, 2047] table, writeable ({tag}) {per_call(lambda: vbq_amd.quantize(mu_bc, sg_bc, lam1, table=tab_w), 500):7.1f} us per call")
+        print(f"facade L=1, NumPy [256, 2047] table, read-only ({tag}) {per_call(lambda: vbq_amd.quantize(mu_bc, sg_bc, lam1, table=tab_ro), 500):7.1f} us per call")
+        api._xxh3 = real
     lc = torch.zeros((32, C, N_BITS + 1), dtype=torch.int64, device=dev)
     print(f"ops.level_counts L=32             {per_call(lambda: ops.level_counts(mu, sg, tab, LAMBDAS, N=N_BITS, layout='cb', out=lc)):7.1f} us per call")
     e = torch.empty(16, device=dev)
