@@ -1204,13 +1204,11 @@ def run_api_methods(torch, dev, mu_h, sg_h, mu_bc, sg_bc, tab_h, steps=10, warmu
             return 0.5 + 0.1 * Z[..., :3]
     vae = _DeviceVAE()
     X = np.zeros((1, H, W, 3), np.float32)
-    seen = {}
+    seen, pinned = {}, {}
 
     def eval_image():
         tmp = q.compress(X, vae, lams, clip=True)
-        seen["sums"] = vutils._sums_per_setting(tmp["num_bits"], lams)
-        seen["sums_cl"] = vutils._sums_per_setting(tmp.get("num_bits_cl", tmp["num_bits"]), lams)
-        seen["x_u8"] = vutils._reconstructions_u8(tmp["X_hat"], lams)
+        seen["sums"], seen["sums_cl"], seen["x_u8"] = vutils.evaluation_reads(tmp, lams, pinned)      # one synchronisation
         seen["tmp"] = tmp
     for _ in range(warmup):
         eval_image()

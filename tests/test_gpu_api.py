@@ -969,6 +969,8 @@ def test_per_image_results_stay_on_the_device_until_read(golden):
     sums = utils._sums_per_setting(out["num_bits"], lambs)
     sums_cl = utils._sums_per_setting(out["num_bits_cl"], lambs)
     u8 = utils._reconstructions_u8(out["X_hat"], lambs)
+    all3 = utils.evaluation_reads(out, lambs, {})                                    # the three of them behind ONE synchronisation
+    assert np.array_equal(all3[0], sums) and np.array_equal(all3[1], sums_cl) and np.array_equal(all3[2], u8)
     assert stager.transfers == 0 and sums.dtype == np.float32 and u8.dtype == np.uint8 and u8.shape == (16,) + X.shape[1:]
     # first host read of ONE quantity: that one (its 16 lambdas at once) + the DMA of its two siblings, not X_hat
     nb = np.asarray(out["num_bits"][lambs[5]])

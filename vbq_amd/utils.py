@@ -193,29 +193,63 @@ def evaluate_compression_jpg(img_file, quality=(1, 10), return_reconstructions=F
     return results
 
 
+def _device_row_sums(d, settings):
+    """Device tensor f32 [M] of np.sum(np.asarray(d[lamb])[0]) per setting in NumPy's float32 order (vbq_numpy_row_sums_f32) when
+    the arrays are device-resident float32 views of one call with a batch of one image; else None."""
+    from .lazy import common_stack
+    t = common_stack([d[lamb] for lamb in settings])
+    if t is not None and t.dtype == torch.float32 and t.dim() >= 2 and t.shape[1] == 1 and t.is_contiguous():
+        return ops.numpy_row_sums(t)
+    return None
+
+
 def _sums_per_setting(d, settings):
     """[np.sum(np.asarray(d[lamb])[0]) for lamb in settings] (utils.py:547-552) as float32 scalars: on the device, in NumPy's
-    own summation order, while the arrays are device-resident float32 views of one call with a batch of one image; on the host
-    otherwise."""
-    from . import ops
+    own summation order, while the arrays are still there; on the host otherwise."""
+    t = _device_row_sums(d, settings)
+    if t is not None:
+        return t.cpu().numpy()
+    return np.array([np.sum(np.asarray(d[lamb])[0]) for lamb in settings])
+
+
+def _device_u8(d, settings):
     from .lazy import common_stack
-    vals = [d[lamb] for lamb in settings]
-    t = common_stack(vals)
-    if t is not None and t.dtype == torch.float32 and t.dim() >= 2 and t.shape[1] == 1 and t.is_contiguous():
-        return ops.numpy_row_sums(t).cpu().numpy()
-    return np.array([np.sum(np.asarray(v)[0]) for v in vals])
+    t = common_stack([d[lamb] for lamb in settings])
+    if t is not None and t.dtype == torch.float32:
+        return (t[:, 0] * 255).round().clamp(0, 255).to(torch.uint8)
+    return None
 
 
 def _reconstructions_u8(d, settings):
     """np.clip(np.round(X_hat * 255), 0, 255).astype(np.uint8) of the first image of every setting (utils.py:554-556) ->
     [M, H, W, 3] uint8 on the host; taken on the device when the reconstructions still live there (a quarter of the bytes
     cross PCIe)."""
-    from .lazy import common_stack
-    vals = [d[lamb] for lamb in settings]
-    t = common_stack(vals)
-    if t is not None and t.dtype == torch.float32:
-        return (t[:, 0] * 255).round().clamp(0, 255).to(torch.uint8).cpu().numpy()
-    return np.stack([np.clip(np.round(np.asarray(v)[0] * 255), 0, 255).astype(np.uint8) for v in vals])
+    t = _device_u8(d, settings)
+    if t is not None:
+        return t.cpu().numpy()
+    return np.stack([np.clip(np.round(np.asarray(d[lamb])[0] * 255), 0, 255).astype(np.uint8) for lamb in settings])
+
+
+def evaluation_reads(tmp, settings, staging=None):
+    """Everything the evaluation loop reads from one `quantizer.compress(...)` result (utils.py:547-556) -> (sums of 'num_bits',
+    sums of 'num_bits_cl', uint8 reconstructions), float32 [M] / float32 [M] / uint8 [M, H, W, 3] on the host.  With
+    device-resident results: three small device tensors, ONE synchronisation (asynchronous copies into pinned memory kept in
+    `staging`, a dict the caller holds between images); no latent-shaped array crosses PCIe."""
+    num_bits_cl = tmp.get("num_bits_cl", tmp["num_bits"])
+    dev = (_device_row_sums(tmp["num_bits"], settings), _device_row_sums(num_bits_cl, settings), _device_u8(tmp["X_hat"], settings))
+    if any(t is None for t in dev):
+        return _sums_per_setting(tmp["num_bits"], settings), _sums_per_setting(num_bits_cl, settings), _reconstructions_u8(tmp["X_hat"], settings)
+    staging = {} if staging is None else staging
+    host = []
+    for i, t in enumerate(dev):
+        h = staging.get(i)
+        if h is None or h.numel() < t.numel() or h.dtype != t.dtype:
+            h = staging[i] = torch.empty(max(t.numel(), 1), dtype=t.dtype, pin_memory=True)
+        hv = h[:t.numel()].view(t.shape)
+        hv.copy_(t, non_blocking=True)
+        host.append(hv)
+    torch.cuda.current_stream(dev[0].device).synchronize()
+    return tuple(np.array(h.numpy()) for h in host)
 
 
 def evaluate_compression_quantizer(quantizer, vae, test_img_files, settings, model_input_float_type="float32",
@@ -235,6 +269,7 @@ def evaluate_compression_quantizer(quantizer, vae, test_img_files, settings, mod
         results[key] = np.empty([N, M])
     modes = ("RGB", "Luma", "Chroma")
     results.update({"%s (%s)" % (metric, mode): np.empty([N, M]) for mode in modes for metric in ("MSE", "PSNR", "MS-SSIM")})
+    staging = {}
     for n, f in enumerate(test_img_files):
         orig = Image.open(f)
         img = orig.convert("RGB")
@@ -242,13 +277,11 @@ def evaluate_compression_quantizer(quantizer, vae, test_img_files, settings, mod
         x = np.asarray(img)
         X = (x / 255.)[None, ...].astype(model_input_float_type)
         tmp = quantizer.compress(X, vae, settings, clip=True)
-        num_bits_cl = tmp.get("num_bits_cl", tmp["num_bits"])
-        # utils.py:547-552: nbits = np.sum(num_bits), np.sum(num_bits_cl) per setting.  While the per-lambda arrays are still on
-        # the device (vbq_amd.lazy) the sums are taken there, in NumPy's own float32 order (vbq_numpy_row_sums_f32), and M floats
-        # come to the host instead of M latent-shaped arrays; otherwise np.sum as in the reference.
-        sums = _sums_per_setting(tmp["num_bits"], settings)
-        sums_cl = _sums_per_setting(num_bits_cl, settings)
-        x_hat_u8 = _reconstructions_u8(tmp["X_hat"], settings)                       # [M, H, W, 3] uint8 (host)
+        # utils.py:547-556: nbits = np.sum(num_bits), np.sum(num_bits_cl) per setting, X_hat as uint8.  While the per-lambda arrays
+        # are still on the device (vbq_amd.lazy) the sums are taken there, in NumPy's own float32 order (vbq_numpy_row_sums_f32),
+        # and 2 M floats + the uint8 images come to the host instead of latent-shaped float arrays; otherwise np.sum as in the
+        # reference.
+        sums, sums_cl, x_hat_u8 = evaluation_reads(tmp, settings, staging)
         img_hats, x_hats = [], []
         for m, lamb in enumerate(settings):
             nbits = sums[m]
