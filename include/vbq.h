@@ -523,6 +523,9 @@ int vbq_analogy_ranks_f32(const float *d_emb, int64_t V, int32_t K, const int32_
  * [B][H][W][C], float64 arithmetic as in the reference.
  *   vbq_image_sqerr_u8   per-image integer sum of (a - b)^2 (mse :6-16 = sum / n, psnr :19-33 from it)
  *   vbq_u8_to_f64        widening copy (img.astype(float64), :122-123)
+ *   vbq_unit_to_u8_f32   np.clip(np.round(X_hat * 255), 0, 255).astype(np.uint8) of the evaluation loop (utils.py:555) on the
+ *                        device: reconstructions in [0, 1] -> the uint8 images the metrics compare (a quarter of the bytes, should
+ *                        they go to the host for PIL's colour conversion)
  *   vbq_ssim_scale_f64   one scale of _SSIMForMultiScale (:84-157): 'valid' Gaussian window given as its
  *                        separable factor d_window[size] (size <= 11), constants c1 = (k1 max_val)^2,
  *                        c2 = (k2 max_val)^2; writes mean ssim and mean cs per image.  Direct sums where the
@@ -532,6 +535,7 @@ int vbq_analogy_ranks_f32(const float *d_emb, int64_t V, int32_t K, const int32_
 int vbq_image_sqerr_u8(const uint8_t *d_img1, const uint8_t *d_img2, int64_t n_images, int64_t n_per_image,
                        int64_t *d_out_sum, void *stream);
 int vbq_u8_to_f64(const uint8_t *d_in, int64_t n, double *d_out, void *stream);
+int vbq_unit_to_u8_f32(const float *d_in, int64_t n, uint8_t *d_out, void *stream);
 size_t vbq_ssim_scale_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t C, int32_t size);
 int vbq_ssim_scale_f64(const double *d_im1, const double *d_im2, int32_t B, int32_t H, int32_t W, int32_t C,
                        const double *d_window, int32_t size, double c1, double c2, double *d_out_ssim,

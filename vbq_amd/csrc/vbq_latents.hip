@@ -244,7 +244,7 @@ k_gather_latents_vec(const uint16_t *__restrict__ idx, long B, int C, const floa
 #ifndef VBQ_LDS_AHEAD
 #define VBQ_LDS_AHEAD 2
 #endif
-constexpr int kLdsRows = 256, kLdsPitch = kLdsRows, kLdsAhead = VBQ_LDS_AHEAD;
+constexpr int kLdsCh = 16, kLdsRows = 256, kLdsPitch = kLdsRows, kLdsAhead = VBQ_LDS_AHEAD;
 // From where the LDS form is taken (C = 256, tools/gather_bench.py and the bench's per-image call).  With uniform random indices it
 // wins from one image on (1 536 rows x 16 lambdas: num_bits 22.8 against 32.8 us); with the indices of a real solve -- a few hot
 // code points per lambda, whose sectors the L2 form's lanes share -- one image is faster in ONE launch of the L2 form (47.7
@@ -252,28 +252,20 @@ constexpr int kLdsRows = 256, kLdsPitch = kLdsRows, kLdsAhead = VBQ_LDS_AHEAD;
 // indices, inside the facade: 1.23 -> 0.84 ms).
 constexpr int64_t kLdsMinLookupsZ = 3 << 14;         // lambdas x rows per channel table (Z_hat, with raw_num_bits riding along)
 constexpr int64_t kLdsMinLookupsNb = 3 << 10;        // rows per (lambda, channel) table (num_bits)
-// CH: channel tables per workgroup (64 CH threads).  16 = one 1024-thread workgroup per CU (128 KB of tables), 64-byte row segments
-// out; 8 = 512 threads and 64 KB of tables, so that TWO workgroups share a CU and one's barrier wait is the other's run time --
-// 32-byte row segments (round-5 experiment, VBQ_LOOKUP_CH=8; numbers in EXPERIMENTS.md).
-template <int N, int CH>
-__global__ void __launch_bounds__(64 * CH)
+template <int N>
+__global__ void __launch_bounds__(1024)
 k_lookup_lds(const uint16_t *__restrict__ idx, long B, int C, int L, const float *__restrict__ tab, int per_lambda,
              float *__restrict__ out_a, long rows_per_split) {
     constexpr int T = table_size(N), TP = T;
     extern __shared__ float lds_f[];
-    constexpr int kLdsCh = CH, G4 = CH / 4;                    // G4: groups of four channels = threads per output row
-    float *tabs = lds_f;                                       // [CH][T]
-    float *tiles = lds_f + ((kLdsCh * TP + 3) & ~3);           // two tiles [CH][256], 16-byte aligned
+    float *tabs = lds_f;                                       // [16][T]
+    float *tiles = lds_f + ((kLdsCh * TP + 3) & ~3);           // two tiles [16][256], 16-byte aligned
     int flip = 0;
     // Workgroups go to the 8 XCDs round-robin by their linear number.  A workgroup writes 64-byte halves of 128-byte lines; with
     // the channel groups renumbered inside every block of 16 so that groups 2k and 2k + 1 get numbers 8 apart, the two halves of a
     // line are written by workgroups of ONE XCD, walking the same rows in the same order, and meet in that XCD's L2.
     int grp = blockIdx.x;
-    if (CH == 16) {
-        if ((gridDim.x & 15) == 0) grp = (grp & ~15) + ((grp & 7) << 1) + ((grp >> 3) & 1);
-    } else {                                                   // four groups of 8 channels per 128-byte line: all four on one XCD
-        if ((gridDim.x & 31) == 0) grp = (grp & ~31) + ((grp & 7) << 2) + ((grp >> 3) & 3);
-    }
+    if ((gridDim.x & 15) == 0) grp = (grp & ~15) + ((grp & 7) << 1) + ((grp >> 3) & 1);
     const int c0 = grp * kLdsCh;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int c = c0 + w;
@@ -313,7 +305,7 @@ k_lookup_lds(const uint16_t *__restrict__ idx, long B, int C, int L, const float
             flip ^= 1;                                          // the tile written two blocks ago is free again: a barrier lies between
             *reinterpret_cast<float4 *>(tile + w * kLdsPitch + ((4 * lane) ^ ((w & 4) << 2))) = make_float4(v[0], v[1], v[2], v[3]);
             __syncthreads();
-            const int row = threadIdx.x / G4, g = threadIdx.x % G4, ch4 = g * 4;
+            const int row = threadIdx.x >> 2, g = threadIdx.x & 3, ch4 = g * 4;
             const int rs = row ^ ((g & 1) << 4);                // (ch4 & 4) << 2: the flip of this channel group's rows
             const long rr = r0 + row;
             if (FULL || (rr < r_end && c0 + ch4 < C))            // C % 4 == 0: four channels are inside or outside together
@@ -359,11 +351,8 @@ int lookup_lds_passes(const uint16_t *idx, int64_t B, int32_t C, int32_t L, cons
         const uintptr_t al = reinterpret_cast<uintptr_t>(out_z) | reinterpret_cast<uintptr_t>(out_nb);
         if (mode == 0 || B % 4 != 0 || C % 4 != 0 || (al & 15) != 0 || (reinterpret_cast<uintptr_t>(idx) & 7) != 0) return VBQ_OK;
         constexpr int TP = table_size(N);
-        static const int ch_env = [] { const char *e = getenv("VBQ_LOOKUP_CH"); return e ? atoi(e) : 16; }();   // A/B: 8 or 16
-        const int kLdsCh = ch_env == 8 ? 8 : 16;
         const size_t lds = sizeof(float) * (size_t)(((kLdsCh * TP + 3) & ~3) + 2 * kLdsCh * kLdsPitch);
         const int groups = (C + kLdsCh - 1) / kLdsCh;
-        const void *kfn = kLdsCh == 8 ? reinterpret_cast<const void *>(&k_lookup_lds<N, 8>) : reinterpret_cast<const void *>(&k_lookup_lds<N, 16>);
         // a staged table entry must be looked up often enough to pay for its staging: measured break-even (tools/gather_bench.py)
         const bool want_z = out_z != nullptr && (mode == 1 || mode == 3 || (mode < 0 && (int64_t)L * B >= kLdsMinLookupsZ));
         const bool want_nb = out_nb != nullptr && (mode == 1 || mode == 2 || (mode < 0 && B >= kLdsMinLookupsNb));
@@ -379,7 +368,8 @@ int lookup_lds_passes(const uint16_t *idx, int64_t B, int32_t C, int32_t L, cons
         }
         signed char state = lds_state[dev].load(std::memory_order_relaxed);
         if (state == 0) {
-            const hipError_t e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lookup_lds<N>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) (void)hipGetLastError();
             state = e == hipSuccess ? 1 : 2;
             lds_state[dev].store(state, std::memory_order_relaxed);
@@ -393,22 +383,14 @@ int lookup_lds_passes(const uint16_t *idx, int64_t B, int32_t C, int32_t L, cons
             const int64_t per = ((blocks + splits - 1) / splits) * kLdsRows;
             splits = (B + per - 1) / per;
             if (splits > 65535) return VBQ_OK;                 // (not reachable with ~2 workgroups per CU; the generic kernel serves it)
-            if (kLdsCh == 8)
-                hipLaunchKernelGGL((k_lookup_lds<N, 8>), dim3((unsigned)groups, (unsigned)splits), dim3(512), lds, st, idx, (long)B, (int)C,
-                                   (int)L, tab_sorted, 0, out_z, (long)per);
-            else
-                hipLaunchKernelGGL((k_lookup_lds<N, 16>), dim3((unsigned)groups, (unsigned)splits), dim3(1024), lds, st, idx, (long)B, (int)C,
-                                   (int)L, tab_sorted, 0, out_z, (long)per);
+            hipLaunchKernelGGL((k_lookup_lds<N>), dim3((unsigned)groups, (unsigned)splits), dim3(1024), lds, st, idx, (long)B, (int)C, (int)L,
+                               tab_sorted, 0, out_z, (long)per);
             VBQ_CHECK_LAUNCH("lookup_lds (sorted table)");
             *did_z = true;
         }
         if (want_nb && L <= 65535) {
-            if (kLdsCh == 8)
-                hipLaunchKernelGGL((k_lookup_lds<N, 8>), dim3((unsigned)groups, (unsigned)L), dim3(512), lds, st, idx, (long)B, (int)C, (int)L,
-                                   models, 1, out_nb, (long)B);
-            else
-                hipLaunchKernelGGL((k_lookup_lds<N, 16>), dim3((unsigned)groups, (unsigned)L), dim3(1024), lds, st, idx, (long)B, (int)C, (int)L,
-                                   models, 1, out_nb, (long)B);
+            hipLaunchKernelGGL((k_lookup_lds<N>), dim3((unsigned)groups, (unsigned)L), dim3(1024), lds, st, idx, (long)B, (int)C, (int)L,
+                               models, 1, out_nb, (long)B);
             VBQ_CHECK_LAUNCH("lookup_lds (entropy models)");
             *did_nb = true;
         }

@@ -190,6 +190,32 @@ extern "C" int vbq_u8_to_f64(const uint8_t *d_in, int64_t n, double *d_out, void
     return VBQ_OK;
 }
 
+namespace vbq {
+namespace {
+// np.clip(np.round(x * 255), 0, 255).astype(np.uint8) (utils.py:555): one f32 multiply, round half to even (np.round = rint),
+// clip, convert.  NaN -> 0 (NumPy's cast of NaN is undefined; the reconstructions are clipped to [0, 1] upstream).
+__global__ void __launch_bounds__(256) k_unit_to_u8(const float *__restrict__ x, long n, uint8_t *__restrict__ out) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        float v = rintf(__fmul_rn(x[i], 255.0f));
+        v = v >= 0.0f ? (v <= 255.0f ? v : 255.0f) : 0.0f;
+        out[i] = (uint8_t)v;
+    }
+}
+}  // namespace
+}  // namespace vbq
+
+extern "C" int vbq_unit_to_u8_f32(const float *d_in, int64_t n, uint8_t *d_out, void *stream) {
+    using namespace vbq;
+    VBQ_REQUIRE(n >= 0, VBQ_ERR_INVALID_ARGUMENT, "vbq_unit_to_u8_f32: n < 0");
+    if (n == 0) return VBQ_OK;
+    VBQ_REQUIRE(d_in && d_out, VBQ_ERR_INVALID_ARGUMENT, "vbq_unit_to_u8_f32: null pointer");
+    int64_t gx = (n + 255) / 256;
+    if (gx > 8192) gx = 8192;
+    hipLaunchKernelGGL(k_unit_to_u8, dim3((unsigned)gx), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), d_in, (long)n, d_out);
+    VBQ_CHECK_LAUNCH("unit_to_u8");
+    return VBQ_OK;
+}
+
 extern "C" size_t vbq_ssim_scale_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t C, int32_t size) {
     if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || size <= 0 || size > H || size > W) return 0;
     const int64_t tx = (W - size + 1 + vbq::kTile - 1) / vbq::kTile, ty = (H - size + 1 + vbq::kTile - 1) / vbq::kTile;

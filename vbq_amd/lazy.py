@@ -11,9 +11,12 @@ take `.tensor` and never trigger a copy.
 
 First host access of a quantity copies THAT quantity of the call -- all its lambdas at once -- through a persistent pinned
 staging block, in three pieces whose transfers overlap the copies out of the block (NumPy releases the GIL for large copies:
-the pieces are copied out by a small thread pool), and starts the DMA of the call's other quantities into their staging
-blocks in the background (no host time): reading everything costs what the eager form cost, reading one quantity a third of
-it, reading nothing nothing.  Not thread-safe (one evaluation loop per quantizer object), like the staging blocks before.
+the pieces are copied out by a small thread pool).  A loop reads the same quantities image after image, so the first access in
+a call also starts the DMA of those siblings that the PREVIOUS call's results were read for: a caller that reads everything pays
+what the eager form paid (the transfers run side by side), one that reads one quantity a third of it, one that reads nothing
+nothing.  (Starting the DMA of ALL siblings was measured and dropped: the copies nobody reads sit on the stream -- and the PCIe
+link -- in front of the next image's work; 3.6 ms per image for num_bits alone.)  Not thread-safe (one evaluation loop per
+quantizer object), like the staging blocks before.
 """
 from __future__ import annotations
 
@@ -41,6 +44,9 @@ class HostStager:
         self._pool = None
         self.transfers = 0                       # device-to-host copies issued (tests read it)
         self.bytes = 0
+        self._group = None                       # the call whose results are being read, what was read of it ...
+        self._reads = set()
+        self._prev_reads = set()                 # ... and what was read of the call before: what to prefetch
 
     def pool(self):
         if self._pool is None:
@@ -62,8 +68,8 @@ class HostStager:
         if h is None or h.numel() < t.numel() or h.dtype != t.dtype:
             h = self.blocks[stack.name] = torch.empty(max(t.numel(), 1), dtype=t.dtype, pin_memory=True)
         st = torch.cuda.current_stream(t.device)
-        if stack.ready is not None:
-            st.wait_event(stack.ready)           # the kernels that produce it may have been enqueued on another stream
+        if stack.stream is not None and stack.stream != st:
+            st.wait_stream(stack.stream)         # the kernels that produce it were enqueued on another stream
         hv = h[:t.numel()].view(t.shape)
         evs = []
         cuts = self._cuts(t.shape[0]) if t.dim() else [0, 1]
@@ -82,9 +88,14 @@ class HostStager:
 
     def fetch(self, stack: "DeviceStack") -> np.ndarray:
         """The host copy of `stack` (a fresh pageable array), its siblings' transfers started on the way."""
+        if self._group is not stack.siblings:    # the first read of another call's results: remember what the last one was read for
+            if self._group is not None:
+                self._prev_reads = self._reads
+            self._group, self._reads = stack.siblings, set()
+        self._reads.add(stack.name)
         self.issue(stack)
         for sib in stack.siblings:
-            if sib is not stack and sib._host is None:
+            if sib is not stack and sib._host is None and sib.name in self._prev_reads:
                 self.issue(sib)
         t = stack.tensor
         h = self.blocks[stack.name][:t.numel()].view(t.shape).numpy()
@@ -110,15 +121,13 @@ class HostStager:
 class DeviceStack:
     """One quantity of one call: a device tensor [L, *shape] and, once somebody has read it, its host copy."""
 
-    def __init__(self, name: str, tensor: torch.Tensor, stager: Optional[HostStager], record_ready: bool = True):
+    def __init__(self, name: str, tensor: torch.Tensor, stager: Optional[HostStager]):
         self.name, self.tensor, self.stager = name, tensor, stager
         self.id = next(_ids)
         self.siblings = [self]
         self._host = None
-        self.ready = None
-        if record_ready and tensor.is_cuda:
-            self.ready = torch.cuda.Event()
-            self.ready.record(torch.cuda.current_stream(tensor.device))
+        # the stream the producing kernels were enqueued on: a copy issued from another stream waits for it
+        self.stream = torch.cuda.current_stream(tensor.device) if tensor.is_cuda else None
 
     @property
     def on_device(self) -> bool:

@@ -314,6 +314,14 @@ def numpy_sum_sq(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def unit_to_u8(x: torch.Tensor) -> torch.Tensor:
+    """vbq_unit_to_u8_f32: np.clip(np.round(x * 255), 0, 255).astype(np.uint8) of a float32 device tensor (utils.py:555)."""
+    x = _dev(x, torch.float32, "x")
+    out = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    check(_lib.lib().vbq_unit_to_u8_f32(_ptr(x), x.numel(), _ptr(out), _stream(x)), "vbq_unit_to_u8_f32")
+    return out
+
+
 def numpy_row_sums(x: torch.Tensor, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
     """vbq_numpy_row_sums_f32: np.sum(x[r]) for every r of a contiguous float32 device tensor [rows, ...], in NumPy's own float32
     summation order (bit for bit) -> f32 [rows] on the device.  The reductions of the evaluation loop (utils.py:547-552) without

@@ -216,7 +216,7 @@ def _device_u8(d, settings):
     from .lazy import common_stack
     t = common_stack([d[lamb] for lamb in settings])
     if t is not None and t.dtype == torch.float32:
-        return (t[:, 0] * 255).round().clamp(0, 255).to(torch.uint8)
+        return ops.unit_to_u8(t[:, 0])
     return None
 
 
