@@ -191,6 +191,37 @@ int vbq_code_lengths_from_counts(const void *d_counts, int32_t counts_are_i32, i
                                  const float *d_lut, int64_t lut_n, int32_t level_period,
                                  float *d_out_len, float *d_out_model, void *stream);
 
+/* The same arithmetic on the HOST, for the count tables that cannot be tabulated (2^24 samples per histogram row or more, fractional
+ * smoothing): model[r][k] = -log2(f32(count[r][k] + n) / sum_k f32(count[r][k] + n)) exactly as quantizer.py:105-110 / 141-146
+ * evaluates it in NumPy float32 (the row sum in NumPy's pairwise order); h_out_len[r][k] = k + model[r][k] when add_level != 0
+ * (the "n + overhead" of :171-175).  h_* are HOST pointers (pinned or not); K <= 8192; either output may be NULL.
+ *   log2_loop / log2_data   the float32 log2 as a NumPy ufunc inner loop (numpy/ufuncobject.h PyUFuncGenericFunction: args[0] in,
+ *                           args[1] out, dimensions[0] elements, byte steps): NumPy's float32 log2 is not libm's, and the
+ *                           reference's numbers are NumPy's -- the Python host hands over np.log2's own loop (vbq_amd/pipeline.py).
+ *                           NULL: libm's log2f.
+ * vbq_host_stage_run(stage) runs it on a filled-in descriptor: the function a caller gives hipLaunchHostFunc to put the step
+ * BETWEEN two device stages of a stream without a synchronisation -- plain C on the runtime's callback thread, no interpreter
+ * lock involved; `status` receives the return code, `runs` counts the executions. */
+typedef void (*vbq_f32_loop)(char **args, const intptr_t *dimensions, const intptr_t *steps, void *data);
+typedef struct vbq_host_stage {
+    const void *h_counts;
+    int32_t counts_are_i32;
+    int32_t add_level;
+    int64_t n_rows;
+    int64_t K;
+    float add_n_smoothing;
+    int32_t status;
+    vbq_f32_loop log2_loop;
+    void *log2_data;
+    float *h_out_model;
+    float *h_out_len;
+    int64_t runs;
+} vbq_host_stage;
+int vbq_host_neg_log2_freq_f32(const void *h_counts, int32_t counts_are_i32, int64_t n_rows, int64_t K, float add_n_smoothing,
+                               int32_t add_level, vbq_f32_loop log2_loop, void *log2_data, float *h_out_model,
+                               float *h_out_len);
+void vbq_host_stage_run(void *stage);
+
 /* ----------------------------------------------------------------------------------
  * K1c  Generic candidate solve.  Replaces utils.batch_quantize_indep_dims
  *      (img-compression/utils.py:363-423) for caller-built candidates, i.e. its

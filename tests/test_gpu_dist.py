@@ -397,7 +397,8 @@ def _host_stage_build(mu, sg, tab, steps, **kw):
     dev = torch.device("cuda", 0)
     mu_d, sg_d = torch.from_numpy(mu).to(dev).reshape(1, -1), torch.from_numpy(sg).to(dev).reshape(1, -1)
     b = EntropyModelBuild(mu.size, 1, HS_LAMBS, torch.from_numpy(tab).to(dev), N=N, add_n_smoothing=1, **kw)
-    assert b.has_host_stages and b.lut1 is None and b.lut2 is None, "the test must take the NumPy-on-the-callback-thread route"
+    assert b.has_host_stages and b.lut1 is None and b.lut2 is None, "the test must take the host-stage route"
+    assert b.host_stage_kind == ("python" if os.environ.get("VBQ_PYTHON_HOST_STAGE") == "1" else "native")
     for _ in range(steps):                        # several steps: both histogram buffers, the model table one step late
         b.run(mu_d, sg_d)
     models = b.finish_models()
@@ -426,7 +427,7 @@ def _host_stage_worker(rank, world, port, out):
 @pytest.mark.timeout(600)
 def test_sharded_build_through_the_host_stage_equals_single_process():
     """Two ranks (one device, gloo) x three steps of a C = 1 build with global_rows >= 2^24: both -log2 steps run as NumPy on the
-    HIP runtime's callback thread, stream-ordered between the kernels and beside the asynchronous all-reduces (both histogram
+    HIP runtime's callback thread (as plain C around NumPy's own log2 loop; the Python form gives the same tables), stream-ordered between the kernels and beside the asynchronous all-reduces (both histogram
     buffers in use, the model table of a step looked up one step late) -- and every rank ends with exactly the histograms,
     length table and models one process computes from all rows, which in turn are the reference's NumPy arithmetic on the
     oracle's counts."""
@@ -436,6 +437,13 @@ def test_sharded_build_through_the_host_stage_equals_single_process():
     from vbq_amd import entropy
     mu, sg, tab = _host_stage_data()
     ref = _host_stage_build(mu, sg, tab, 2)
+    # plain C with NumPy's log2 loop (no interpreter lock on the callback thread) == NumPy in Python on that thread
+    os.environ["VBQ_PYTHON_HOST_STAGE"] = "1"
+    try:
+        ref_py = _host_stage_build(mu, sg, tab, 2)
+    finally:
+        del os.environ["VBQ_PYTHON_HOST_STAGE"]
+    assert all(np.array_equal(a, b) for a, b in zip(ref, ref_py))
     # the single-process build itself against the oracle: level histogram of pass 1, models = NumPy float32 ops on the counts
     lev = O.levels_of_sorted_ranks(N)
     n = 300_000

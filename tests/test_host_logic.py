@@ -363,3 +363,41 @@ def test_lazy_array_behaves_like_the_ndarray_it_stands_for():
         len(DeviceStack("s", torch.zeros(3), None).rows()[0])
     s0 = DeviceStack("s", torch.arange(3, dtype=torch.float32), None).rows()[1]
     assert float(s0) == 1.0 and int(s0) == 1 and bool(s0) and s0.shape == ()
+
+
+def test_native_host_stage_arithmetic_is_numpys():
+    """vbq_host_neg_log2_freq_f32 (the -log2 step as plain C for the runtime's callback thread) == entropy.neg_log2_freq, i.e.
+    the reference's NumPy float32 operations (quantizer.py:105-110, 141-146, 171-175), bit for bit: int32 / int64 counts whose
+    float32 conversions and row sums round (> 2^24), integer and fractional smoothing, the row lengths of N = 4 ... 12 -- with
+    np.log2's own inner loop, found in the ufunc object and accepted only after this very comparison; through the descriptor
+    form (what hipLaunchHostFunc calls) as well; libm's log2f (NULL loop) agrees to an ulp, not to the bit."""
+    import ctypes as C
+    from vbq_amd import _lib
+    from vbq_amd.pipeline import numpy_log2_f32_loop
+    h = _lib.lib()
+    loop = numpy_log2_f32_loop()
+    assert loop is not None and loop[0], "np.log2's float32 inner loop was not found (the builds would fall back to the Python stage)"
+    rng = np.random.default_rng(11)
+    for K, rows, dt in ((11, 96, np.int64), (2047, 33, np.int32), (31, 7, np.int64), (4095, 5, np.int32), (8191, 3, np.int64), (5, 9, np.int32)):
+        for sm in (1, 0.5, 2):
+            cnt = rng.gamma(0.3, 6e7 / K, (rows, K)).astype(dt)
+            cnt[0, :] = 0
+            want = entropy.neg_log2_freq(cnt, sm)
+            model, ln = np.empty((rows, K), np.float32), np.empty((rows, K), np.float32)
+            assert h.vbq_host_neg_log2_freq_f32(cnt.ctypes.data, int(dt == np.int32), rows, K, float(sm), 1, loop[0], loop[1],
+                                                model.ctypes.data, ln.ctypes.data) == 0
+            assert np.array_equal(model, want) and np.array_equal(ln, (np.arange(K, dtype=np.float32) + want).astype(np.float32)), (K, sm)
+            d = _lib.HostStageDesc()
+            out2 = np.full((rows, K), -1, np.float32)
+            d.h_counts, d.counts_are_i32, d.add_level, d.n_rows, d.K, d.add_n_smoothing = cnt.ctypes.data, int(dt == np.int32), 0, rows, K, float(sm)
+            d.log2_loop, d.log2_data, d.h_out_model, d.h_out_len, d.status, d.runs = loop[0], loop[1], out2.ctypes.data, None, 77, 0
+            h.vbq_host_stage_run(C.byref(d))
+            assert d.status == 0 and d.runs == 1 and np.array_equal(out2, want)
+            libm = np.empty((rows, K), np.float32)
+            assert h.vbq_host_neg_log2_freq_f32(cnt.ctypes.data, int(dt == np.int32), rows, K, float(sm), 0, None, None, libm.ctypes.data, None) == 0
+            np.testing.assert_allclose(libm, want, rtol=3e-7)
+    assert h.vbq_host_neg_log2_freq_f32(None, 0, 3, 9000, 1.0, 0, None, None, None, None) == -1 and b"8192" in h.vbq_last_error()
+    d = _lib.HostStageDesc()
+    d.n_rows, d.K = 2, 5                                                  # a descriptor without buffers: the status says so
+    h.vbq_host_stage_run(C.byref(d))
+    assert d.status == -1 and d.runs == 1

@@ -40,6 +40,9 @@ SIGNATURES = {
                                        C.c_int32, C.c_void_p]),
     "vbq_code_lengths_from_counts": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_int64, C.c_int32,
                                                C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vbq_host_neg_log2_freq_f32": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_float, C.c_int32, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_void_p]),
+    "vbq_host_stage_run": (None, [C.c_void_p]),
     "vbq_histogram_rows_u16": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                          C.c_int32, C.c_int64, C.c_int64, C.c_void_p]),
     "vbq_xi_intervals_f64": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -110,6 +113,13 @@ SIGNATURES = {
                                       C.c_void_p, C.c_void_p, C.c_void_p]),
     "vbq_bmshj_nll_grad_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
 }
+
+
+class HostStageDesc(C.Structure):
+    """include/vbq.h: vbq_host_stage."""
+    _fields_ = [("h_counts", C.c_void_p), ("counts_are_i32", C.c_int32), ("add_level", C.c_int32), ("n_rows", C.c_int64),
+                ("K", C.c_int64), ("add_n_smoothing", C.c_float), ("status", C.c_int32), ("log2_loop", C.c_void_p),
+                ("log2_data", C.c_void_p), ("h_out_model", C.c_void_p), ("h_out_len", C.c_void_p), ("runs", C.c_int64)]
 
 
 class VBQError(RuntimeError):

@@ -20,7 +20,7 @@ LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libvbq_hip.so")
 INCLUDE = os.path.join(ROOT, "include")
 HIP_SOURCES = ["vbq_api.hip", "vbq_quantize.hip", "vbq_quantize_fast.hip", "vbq_hist.hip", "vbq_notebook.hip", "vbq_bmshj.hip",
-               "vbq_candidates.hip", "vbq_latents.hip", "vbq_rans.hip", "vbq_comm.hip", "vbq_xi.hip", "vbq_baselines.hip", "vbq_ranks.hip", "vbq_metrics.hip"]
+               "vbq_candidates.hip", "vbq_latents.hip", "vbq_host.hip", "vbq_rans.hip", "vbq_comm.hip", "vbq_xi.hip", "vbq_baselines.hip", "vbq_ranks.hip", "vbq_metrics.hip"]
 LINK_LIBS = ["-ldl"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
                # every f32/f64 op of the reference is a separately rounded op: never contract a*b+c

@@ -13,8 +13,10 @@ Nothing synchronises with the host.  When the -log2 step can be tabulated (entro
 histogram holds the same number of samples, so -log2(f32(k + n) / f32(total)) is a function of the count k alone and
 the table is built once, on the host, with the reference's own NumPy float32 operations) it is a device lookup.  When
 it cannot (2^24 samples per row or more, fractional smoothing) the small count tables go through a STREAM-ORDERED host
-stage (`HostStage`: asynchronous copy into pinned memory, hipLaunchHostFunc running the reference's NumPy operations,
-asynchronous copy back): still no synchronisation, and the whole step still replays from one HIP graph.
+stage (asynchronous copy into pinned memory, hipLaunchHostFunc, asynchronous copy back): still no synchronisation, and the
+whole step still replays from one HIP graph.  The host function is plain C (`NativeHostStage`: the library's
+vbq_host_stage_run with NumPy's own float32 log2 inner loop -- no interpreter lock on the runtime's thread) or, where that
+loop cannot be had, the reference's NumPy operations in Python (`HostStage`).
 
 `bench.py` times exactly this object; `ChannelwisePriorCDFQuantizer.build_entropy_models` runs it.
 """
@@ -98,6 +100,85 @@ class HostStage:
         if self.error is not None:
             e, self.error = self.error, None
             raise VBQError(f"host stage failed: {type(e).__name__}: {e}") from e
+
+
+class _PyUFuncObject(_C.Structure):
+    """The head of numpy/ufuncobject.h's PyUFuncObject (a public struct, unchanged from NumPy 1.x to 2.x up to `types`)."""
+    _fields_ = [("ob_refcnt", _C.c_ssize_t), ("ob_type", _C.c_void_p), ("nin", _C.c_int), ("nout", _C.c_int), ("nargs", _C.c_int),
+                ("identity", _C.c_int), ("functions", _C.POINTER(_C.c_void_p)), ("data", _C.POINTER(_C.c_void_p)),
+                ("ntypes", _C.c_int), ("reserved1", _C.c_int), ("name", _C.c_char_p), ("types", _C.POINTER(_C.c_char))]
+
+
+_LOG2_LOOP = None          # (function pointer, data pointer) of np.log2's float32 inner loop; False: not usable here
+
+
+def numpy_log2_f32_loop():
+    """NumPy's own float32 log2 as a C function pointer (the first float32 -> float32 inner loop of the np.log2 ufunc object:
+    the one NumPy's type resolution picks), so that a host function WITHOUT the interpreter lock can produce the reference's
+    numbers -- NumPy's float32 log2 is neither libm's nor correctly rounded.  Trusted only after the library's host routine,
+    driven by it, has reproduced entropy.neg_log2_freq bit for bit on a random table; None otherwise (the callers then keep the
+    Python stage)."""
+    global _LOG2_LOOP
+    if _LOG2_LOOP is None:
+        _LOG2_LOOP = False
+        try:
+            u = _PyUFuncObject.from_address(id(np.log2))
+            NPY_FLOAT = 11
+            if u.name == b"log2" and u.nin == 1 and u.nout == 1 and u.nargs == 2 and 0 < u.ntypes < 64:
+                for i in range(u.ntypes):
+                    if ord(u.types[2 * i]) == NPY_FLOAT and ord(u.types[2 * i + 1]) == NPY_FLOAT and u.functions[i]:
+                        cand = (int(u.functions[i]), int(u.data[i] or 0))
+                        rng = np.random.default_rng(7)
+                        ok = True
+                        for K, dt, sm in ((11, np.int64, 1), (2047, np.int32, 1), (257, np.int64, 0.5)):
+                            cnt = rng.gamma(0.3, 4e7 / K, (5, K)).astype(dt)
+                            got = np.empty((5, K), np.float32)
+                            rc = ops._lib.lib().vbq_host_neg_log2_freq_f32(cnt.ctypes.data, int(dt == np.int32), 5, K, float(sm), 0,
+                                                                          cand[0], cand[1], got.ctypes.data, None)
+                            ok = ok and rc == 0 and np.array_equal(got, _entropy.neg_log2_freq(cnt, sm))
+                        if ok:
+                            _LOG2_LOOP = cand
+                        break
+        except Exception:                                       # an interpreter / NumPy build this does not understand
+            _LOG2_LOOP = False
+    return _LOG2_LOOP or None
+
+
+class NativeHostStage:
+    """HostStage for the -log2 step with NO Python on the runtime's callback thread: the callback is the library's
+    vbq_host_stage_run (plain C; NumPy's float32 log2 through its own inner loop, see numpy_log2_f32_loop), so the hazard of
+    HostStage -- a thread that holds the interpreter lock while it blocks on the device with the host node pending -- does not
+    exist.  counts [..., K] (int32 / int64, device) -> out_model (-log2 of the smoothed frequencies) and, optionally, out_len
+    (level + that: quantizer.py:171-175), float32 device tensors of the same shape."""
+
+    def __init__(self, counts: torch.Tensor, out_model: torch.Tensor, out_len: Optional[torch.Tensor], add_n_smoothing, loop):
+        self.counts, self.out_model, self.out_len = counts, out_model, out_len
+        self.h_in = torch.empty(counts.shape, dtype=counts.dtype, pin_memory=True)
+        self.h_model = torch.empty(counts.shape, dtype=torch.float32, pin_memory=True)
+        self.h_len = torch.empty(counts.shape, dtype=torch.float32, pin_memory=True) if out_len is not None else None
+        K = counts.shape[-1]
+        d = self.desc = ops._lib.HostStageDesc()
+        d.h_counts, d.counts_are_i32, d.add_level = self.h_in.data_ptr(), int(counts.dtype == torch.int32), int(out_len is not None)
+        d.n_rows, d.K, d.add_n_smoothing, d.status, d.runs = counts.numel() // K, K, float(add_n_smoothing), 0, 0
+        d.log2_loop, d.log2_data = loop
+        d.h_out_model, d.h_out_len = self.h_model.data_ptr(), (self.h_len.data_ptr() if self.h_len is not None else None)
+        self._fn = _C.cast(ops._lib.lib().vbq_host_stage_run, _C.c_void_p)
+        self.error = None
+
+    def enqueue(self):
+        st = torch.cuda.current_stream(self.counts.device)
+        self.h_in.copy_(self.counts, non_blocking=True)
+        rc = _hip_runtime().hipLaunchHostFunc(_C.c_void_p(st.cuda_stream), self._fn, _C.byref(self.desc))
+        if rc != 0:
+            raise VBQError(f"hipLaunchHostFunc failed ({rc})")
+        self.out_model.copy_(self.h_model, non_blocking=True)
+        if self.out_len is not None:
+            self.out_len.copy_(self.h_len, non_blocking=True)
+
+    def check(self):
+        if self.desc.status != 0:
+            rc, self.desc.status = self.desc.status, 0
+            raise VBQError(f"host stage failed: vbq_host_neg_log2_freq_f32 returned {rc}")
 
 
 def chunk_bounds(rows: int, n_chunks: int, unit: int = 2048):
@@ -186,11 +267,24 @@ class EntropyModelBuild:
             raw = _entropy.neg_log2_freq(level_counts, smooth)
             return (lv + raw).astype(np.float32), raw
 
-        self._len_stage = HostStage([self.level_counts], [self.level_len, self.raw_models], lengths_host) if self.lut1 is None else None
+        # The -log2 steps that cannot be tabulated: plain C on the runtime's callback thread with NumPy's own log2 loop
+        # (NativeHostStage) when this interpreter lets us have it and the smoothing is a Python number (a NumPy float64 scalar
+        # would make `c += n` a float64 addition); otherwise -- or with VBQ_PYTHON_HOST_STAGE=1 -- NumPy itself on that thread.
+        loop = None
+        if type(add_n_smoothing) in (int, float) and T <= 8192 and _os.environ.get("VBQ_PYTHON_HOST_STAGE") != "1":
+            loop = numpy_log2_f32_loop()
+        self.host_stage_kind = None
+        self._len_stage = None
+        if self.lut1 is None:
+            self._len_stage = NativeHostStage(self.level_counts, self.raw_models, self.level_len, add_n_smoothing, loop) if loop else \
+                HostStage([self.level_counts], [self.level_len, self.raw_models], lengths_host)
+            self.host_stage_kind = "native" if loop else "python"
         self._model_stages = None
         if self.lut2 is None and self.models is not None:      # quantizer.py:141-146 on the (global) rank counts
-            self._model_stages = [HostStage([c], [self.models], lambda counts: _entropy.neg_log2_freq(counts, smooth))
+            self._model_stages = [NativeHostStage(c, self.models, None, add_n_smoothing, loop) if loop else
+                                  HostStage([c], [self.models], lambda counts: _entropy.neg_log2_freq(counts, smooth))
                                   for c in self._counts2]
+            self.host_stage_kind = "native" if loop else "python"
         if n_chunks is None:
             # Measured on the Kodak-24 sweep (profiles/r2_overlap_sweep.txt): K2 one chunk behind K1 on a second stream
             # is SLOWER than running them back to back (1.06 / 1.10 / 1.19 ms per step with 2 / 3 / 6 chunks against
@@ -387,7 +481,8 @@ class EntropyModelBuild:
 
     @property
     def has_host_stages(self) -> bool:
-        """Some -log2 step of this build runs NumPy on the HIP runtime's callback thread (HostStage)."""
+        """Some -log2 step of this build runs on the HIP runtime's callback thread (`host_stage_kind`: "native" = plain C with
+        NumPy's log2 loop; "python" = NumPy in Python, which needs the interpreter lock there)."""
         return self._len_stage is not None or bool(self._model_stages)
 
     @property
@@ -398,14 +493,18 @@ class EntropyModelBuild:
     @property
     def length_table_route(self) -> str:
         return "device (tabulated -log2)" if self.lut1 is not None else \
-            "stream-ordered host stage (NumPy float32 -log2 on [L, C, N+1] counts, hipLaunchHostFunc; no synchronisation)"
+            f"stream-ordered host stage ({self._stage_text()} on [L, C, N+1] counts, hipLaunchHostFunc; no synchronisation)"
 
     @property
     def models_route(self) -> str:
         if self.models is None:
             return "not in the step (counts stay on the device)"
         return "device (tabulated -log2)" if self.lut2 is not None else \
-            "stream-ordered host stage (NumPy float32 -log2 on [L, C, T] counts, hipLaunchHostFunc; no synchronisation)"
+            f"stream-ordered host stage ({self._stage_text()} on [L, C, T] counts, hipLaunchHostFunc; no synchronisation)"
+
+    def _stage_text(self) -> str:
+        return "plain C with NumPy's float32 log2 loop, no interpreter lock" if self.host_stage_kind == "native" else \
+            "NumPy float32 -log2 in Python"
 
     def check(self):
         """Outside the timed region (synchronises): the assumptions no kernel can see.  (1) The tabulated -log2 is only valid
