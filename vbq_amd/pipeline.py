@@ -124,10 +124,10 @@ def numpy_log2_f32_loop():
         try:
             u = _PyUFuncObject.from_address(id(np.log2))
             NPY_FLOAT = 11
-            if u.name == b"log2" and u.nin == 1 and u.nout == 1 and u.nargs == 2 and 0 < u.ntypes < 64:
+            if u.name == b"log2" and u.nin == 1 and u.nout == 1 and u.nargs == 2 and 0 < u.ntypes < 64 and u.functions and u.types:
                 for i in range(u.ntypes):
                     if ord(u.types[2 * i]) == NPY_FLOAT and ord(u.types[2 * i + 1]) == NPY_FLOAT and u.functions[i]:
-                        cand = (int(u.functions[i]), int(u.data[i] or 0))
+                        cand = (int(u.functions[i]), int((u.data[i] if u.data else 0) or 0))
                         rng = np.random.default_rng(7)
                         ok = True
                         for K, dt, sm in ((11, np.int64, 1), (2047, np.int32, 1), (257, np.int64, 0.5)):
