@@ -27,6 +27,8 @@ import numpy as np
 import torch
 from numpy.lib.mixins import NDArrayOperatorsMixin
 
+from .ops import raw_stream as _raw_stream
+
 _PIECES = 3
 _THREADED_FROM = 1 << 22           # bytes: below this one plain copy is faster than waking the pool
 _ids = itertools.count(1)
@@ -68,8 +70,8 @@ class HostStager:
         if h is None or h.numel() < t.numel() or h.dtype != t.dtype:
             h = self.blocks[stack.name] = torch.empty(max(t.numel(), 1), dtype=t.dtype, pin_memory=True)
         st = torch.cuda.current_stream(t.device)
-        if stack.stream is not None and stack.stream != st:
-            st.wait_stream(stack.stream)         # the kernels that produce it were enqueued on another stream
+        if stack.stream is not None and stack.stream != st.cuda_stream:
+            st.wait_stream(torch.cuda.ExternalStream(stack.stream, device=t.device))      # produced on another stream
         hv = h[:t.numel()].view(t.shape)
         evs = []
         cuts = self._cuts(t.shape[0]) if t.dim() else [0, 1]
@@ -126,8 +128,8 @@ class DeviceStack:
         self.id = next(_ids)
         self.siblings = [self]
         self._host = None
-        # the stream the producing kernels were enqueued on: a copy issued from another stream waits for it
-        self.stream = torch.cuda.current_stream(tensor.device) if tensor.is_cuda else None
+        # the stream the producing kernels were enqueued on (its raw handle): a copy issued from another stream waits for it
+        self.stream = _raw_stream(tensor.device) if tensor.is_cuda else None
 
     @property
     def on_device(self) -> bool:
@@ -269,11 +271,12 @@ def common_stack(values) -> Optional[torch.Tensor]:
     """When `values` are the LazyArrays 0, 1, 2, ... of ONE DeviceStack, in order: that stack's device tensor [L, ...] (a
     consumer can then work on all lambdas at once); else None."""
     values = list(values)
-    if not values or not all(isinstance(v, LazyArray) for v in values):
+    if not values or type(values[0]) is not LazyArray:
         return None
     st = values[0]._stack
-    if any(v._stack is not st for v in values):
-        return None
+    for v in values:
+        if type(v) is not LazyArray or v._stack is not st:
+            return None
     idx = [v._i for v in values]
     if idx == list(range(st.tensor.shape[0])):
         return st.tensor
