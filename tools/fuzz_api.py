@@ -84,7 +84,7 @@ def one_case(rng, dev):
         for a, b in zip(cuts[:-1], cuts[1:]):
             ops.quantize(torch.from_numpy(m_in).to(dev), torch.from_numpy(s_in).to(dev), torch.from_numpy(tab).to(dev), list(lam), N=N,
                          level_len=None if ll is None else torch.from_numpy(ll).to(dev), layout=layout, out_idx=idx2, rows=(a, b),
-                         workgroups_per_cu=int(rng.choice([0, 4])))
+                         workgroups_per_cu=int(rng.choice([0, 4])), reserved_workgroups=[None, 0, 64, 900][int(rng.integers(0, 4))])
             ops.histogram(idx2, C, N=N, layout=layout, out=cnt2, rows=(a, b))
         miss += int((canon(idx2) != want[0]).sum()) + int((cnt2.cpu().numpy() != hw).sum())
     # the counting kernels (K1t for raw lengths at N = 10, K1h otherwise): bit-length histogram of the same solve
@@ -92,7 +92,8 @@ def one_case(rng, dev):
     if mode == "f32" and in_range and (C == 1 or layout == "cb" or rng.random() < 0.5):
         lay = layout if (C == 1 or layout == "cb") else "bc->cb"
         lc = ops.level_counts(torch.from_numpy(m_in).to(dev), torch.from_numpy(s_in).to(dev), torch.from_numpy(tab).to(dev), list(lam), N=N,
-                              level_len=None if ll is None else torch.from_numpy(ll).to(dev), layout=lay).cpu().numpy()
+                              level_len=None if ll is None else torch.from_numpy(ll).to(dev), layout=lay,
+                              reserved_workgroups=[None, 0, 64, 900][int(rng.integers(0, 4))]).cpu().numpy()
         k = np.arange(1, T + 1)
         lev = N - np.log2(k & -k).astype(np.int64)
         wl = np.zeros((L, C, N + 1), np.int64)
