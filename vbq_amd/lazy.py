@@ -10,8 +10,7 @@ a value is read on the host; consumers that know about the device (`compress` wi
 take `.tensor` and never trigger a copy.
 
 First host access of a quantity copies THAT quantity of the call -- all its lambdas at once -- through a persistent pinned
-staging block, in three pieces whose transfers overlap the copies out of the block (NumPy releases the GIL for large copies:
-the pieces are copied out by a small thread pool).  A loop reads the same quantities image after image, so the first access in
+staging block and out of it into an ordinary array (a pool thread: NumPy releases the GIL for large copies).  A loop reads the same quantities image after image, so the first access in
 a call also starts the DMA of those siblings that the PREVIOUS call's results were read for: a caller that reads everything pays
 what the eager form paid (the transfers run side by side), one that reads one quantity a third of it, one that reads nothing
 nothing.  (Starting the DMA of ALL siblings was measured and dropped: the copies nobody reads sit on the stream -- and the PCIe
@@ -29,20 +28,24 @@ from numpy.lib.mixins import NDArrayOperatorsMixin
 
 from .ops import raw_stream as _raw_stream
 
-_PIECES = 3
-_THREADED_FROM = 1 << 22           # bytes: below this one plain copy is faster than waking the pool
+_THREADS = 3
+_THREADED_FROM = 1 << 20           # bytes: below this the calling thread copies (waking the pool costs more)
 _ids = itertools.count(1)
 
 
 class HostStager:
     """The persistent pinned staging blocks of one quantizer (one per quantity name, grown on demand) and the small thread
     pool that copies results out of them into ordinary pageable arrays -- so that a result kept for later does not pin
-    page-locked memory (an evaluation loop over a data set would otherwise accumulate GBs of it)."""
+    page-locked memory (an evaluation loop over a data set would otherwise accumulate GBs of it).
+
+    One asynchronous device -> staging copy per quantity and ONE pool thread per quantity that waits for it and makes the array
+    (`np.array` of the staging view: its own allocation, so the three threads fault their pages in separate mappings).  Measured
+    (`tools/d2h_bench.py`, 3 x 25 MB): 2.5 ms like this; 3.2-4.4 ms with every quantity cut into pieces for three threads filling
+    one array (page faults of one mapping from three threads); 1.4 ms is the DMA alone, 11.5 ms three `tensor.cpu()`."""
 
     def __init__(self):
         self.blocks: Dict[str, torch.Tensor] = {}
-        self.owner: Dict[str, int] = {}          # id of the DeviceStack whose data the block holds / is receiving
-        self.events: Dict[str, list] = {}
+        self.busy: Dict[str, object] = {}        # the copy-out still reading a block (a Future): a new DMA into it waits for that
         self._pool = None
         self.transfers = 0                       # device-to-host copies issued (tests read it)
         self.bytes = 0
@@ -53,19 +56,17 @@ class HostStager:
     def pool(self):
         if self._pool is None:
             from concurrent.futures import ThreadPoolExecutor
-            self._pool = ThreadPoolExecutor(max_workers=_PIECES)
+            self._pool = ThreadPoolExecutor(max_workers=_THREADS)
         return self._pool
 
-    @staticmethod
-    def _cuts(n0: int):
-        k = min(_PIECES, max(1, n0))
-        return [(n0 * j) // k for j in range(k + 1)]
-
-    def issue(self, stack: "DeviceStack"):
-        """Asynchronous device -> staging copies of `stack` (pieces along its first axis, one event each)."""
-        t = stack.tensor
-        if self.owner.get(stack.name) == stack.id:
+    def start(self, stack: "DeviceStack"):
+        """Asynchronous device -> staging copy of `stack` and the pool task that turns it into an array (stack._future)."""
+        if stack._future is not None or stack._host is not None:
             return
+        t = stack.tensor
+        prev = self.busy.get(stack.name)
+        if prev is not None:
+            prev.result()                        # a prefetched sibling of an earlier call nobody has read yet: let its copy finish
         h = self.blocks.get(stack.name)
         if h is None or h.numel() < t.numel() or h.dtype != t.dtype:
             h = self.blocks[stack.name] = torch.empty(max(t.numel(), 1), dtype=t.dtype, pin_memory=True)
@@ -73,51 +74,41 @@ class HostStager:
         if stack.stream is not None and stack.stream != st.cuda_stream:
             st.wait_stream(torch.cuda.ExternalStream(stack.stream, device=t.device))      # produced on another stream
         hv = h[:t.numel()].view(t.shape)
-        evs = []
-        cuts = self._cuts(t.shape[0]) if t.dim() else [0, 1]
-        for a, b in zip(cuts[:-1], cuts[1:]):
-            if t.dim():
-                hv[a:b].copy_(t[a:b], non_blocking=True)
-            else:
-                hv.copy_(t, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record(st)
-            evs.append(ev)
-        self.owner[stack.name] = stack.id
-        self.events[stack.name] = evs
+        hv.copy_(t, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(st)
         self.transfers += 1
         self.bytes += t.numel() * t.element_size()
 
+        def land():
+            ev.synchronize()
+            return np.array(hv.numpy())          # a fresh pageable array; the block is free again afterwards
+        if t.numel() * t.element_size() >= _THREADED_FROM:
+            stack._future = self.busy[stack.name] = self.pool().submit(land)
+        else:
+            stack._future = _Done(land())
+
     def fetch(self, stack: "DeviceStack") -> np.ndarray:
-        """The host copy of `stack` (a fresh pageable array), its siblings' transfers started on the way."""
+        """The host copy of `stack`; on the way the transfers of those siblings the PREVIOUS call's results were read for."""
         if self._group is not stack.siblings:    # the first read of another call's results: remember what the last one was read for
             if self._group is not None:
                 self._prev_reads = self._reads
             self._group, self._reads = stack.siblings, set()
         self._reads.add(stack.name)
-        self.issue(stack)
+        self.start(stack)
         for sib in stack.siblings:
-            if sib is not stack and sib._host is None and sib.name in self._prev_reads:
-                self.issue(sib)
-        t = stack.tensor
-        h = self.blocks[stack.name][:t.numel()].view(t.shape).numpy()
-        evs = self.events[stack.name]
-        out = np.empty(t.shape, dtype=h.dtype)
-        if t.dim() == 0 or t.numel() == 0:
-            evs[-1].synchronize()
-            out[...] = h
-            return out
-        cuts = self._cuts(t.shape[0])
-
-        def piece(j):
-            evs[j].synchronize()
-            np.copyto(out[cuts[j]:cuts[j + 1]], h[cuts[j]:cuts[j + 1]])
-        if t.numel() * t.element_size() >= _THREADED_FROM and len(evs) > 1:
-            list(self.pool().map(piece, range(len(evs))))
-        else:
-            for j in range(len(evs)):
-                piece(j)
+            if sib is not stack and sib.name in self._prev_reads:
+                self.start(sib)
+        out, stack._future = stack._future.result(), None
         return out
+
+
+class _Done:
+    def __init__(self, value):
+        self.value = value
+
+    def result(self):
+        return self.value
 
 
 class DeviceStack:
@@ -128,6 +119,7 @@ class DeviceStack:
         self.id = next(_ids)
         self.siblings = [self]
         self._host = None
+        self._future = None                      # a transfer under way (HostStager.start)
         # the stream the producing kernels were enqueued on (its raw handle): a copy issued from another stream waits for it
         self.stream = _raw_stream(tensor.device) if tensor.is_cuda else None
 
