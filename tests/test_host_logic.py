@@ -328,7 +328,7 @@ def test_lazy_array_behaves_like_the_ndarray_it_stands_for():
     b = rng.integers(0, 11, size=(4, 1, 3, 5)).astype(np.int32)
     sa, sb = group([DeviceStack("Z_hat", torch.from_numpy(a.copy()), None), DeviceStack("raw_num_bits", torch.from_numpy(b.copy()), None), None])
     rows, rows_b = sa.rows(), sb.rows()
-    assert len(rows) == 4 and all(isinstance(r, LazyArray) for r in rows) and sa.siblings == [sa, sb]
+    assert len(rows) == 4 and all(isinstance(r, LazyArray) for r in rows) and [r() for r in sa.siblings] == [sa, sb] and sa.group == sb.group
     r = rows[2]
     assert r.shape == (1, 3, 5) and r.dtype == np.float32 and r.ndim == 3 and r.size == 15 and len(r) == 1 and r.nbytes == 60
     assert np.shape(r) == (1, 3, 5) and rows_b[0].dtype == np.int32
@@ -401,3 +401,35 @@ def test_native_host_stage_arithmetic_is_numpys():
     d.n_rows, d.K = 2, 5                                                  # a descriptor without buffers: the status says so
     h.vbq_host_stage_run(C.byref(d))
     assert d.status == -1 and d.runs == 1
+
+
+def test_lazy_results_recycle_only_arrays_nobody_holds():
+    """HostStager keeps the host array of a dropped result for the next call's -- but only when no view of it is alive anywhere
+    (every np.asarray(lazy) is a view and holds a reference)."""
+    from vbq_amd.lazy import DeviceStack, HostStager
+    import vbq_amd.lazy as LZ
+    st = HostStager()
+    old = LZ._THREADED_FROM
+    LZ._THREADED_FROM = 16
+    try:
+        def make():
+            s = DeviceStack("q", torch.zeros(4, 8), st)
+            s._host = np.arange(32, dtype=np.float32).reshape(4, 8).copy()   # as if it had been read
+            return s
+        s = make()
+        del s
+        assert len(st.spare["q"]) == 1
+        st.spare["q"].clear()
+        s = make()
+        view = np.asarray(s.rows()[2])                       # the caller keeps a row
+        del s
+        assert st.spare["q"] == [] and view[3] == 19.0        # not recycled: the row is still the caller's
+        s = make()
+        base = s._host
+        del s
+        assert st.spare["q"] == [] and base[0, 0] == 0.0      # nor when the whole array is held
+        s1, s2 = make(), make()
+        del s1, s2
+        assert len(st.spare["q"]) == 1                        # one spare per quantity is enough for a loop
+    finally:
+        LZ._THREADED_FROM = old

@@ -108,3 +108,41 @@ for name, f in (("DMA only (75 MB into pinned)", v_dma_only), ("per quantity: pi
     r = f()
     ok = r is None or all(np.array_equal(a, b) for a, b in zip(r, ref))
     print(f"{name:45s} {ms:7.3f} ms  ok={ok}")
+
+# ---- the same through the quantizer: compress_latents with NumPy in / out (lazy views), everything read / num_bits alone
+import vbq_amd
+from bench import LAMBDAS_16, N_BITS, make_inputs_with_table
+
+rows, C = 36864, 256
+mu_h, sg_h, tab_h = make_inputs_with_table(rows, C, 1000)
+mu_bc, sg_bc = torch.from_numpy(mu_h).to(dev), torch.from_numpy(sg_h).to(dev)
+
+
+class _Table:
+    def inverse_cdf(self, xi):
+        return np.ascontiguousarray(tab_h.T)
+
+
+q = vbq_amd.ChannelwisePriorCDFQuantizer(C, N_BITS)
+q.build_code_points(_Table())
+q.build_entropy_models_from_latents(mu_bc, sg_bc, LAMBDAS_16, 1)
+m_np = mu_h[:1536].reshape(1, 32, 48, C).copy()
+lv_np = (2 * np.log(sg_h[:1536])).astype(np.float32).reshape(1, 32, 48, C)
+m_d, lv_d = torch.from_numpy(m_np).to(dev), torch.from_numpy(lv_np).to(dev)
+
+
+def call(read, device_in=False):
+    o = q.compress_latents(m_d if device_in else m_np, lv_d if device_in else lv_np, LAMBDAS_16)
+    for k in read:
+        np.asarray(o[k][LAMBDAS_16[0]])
+    return None
+
+
+for name, f in (("compress_latents NumPy in, nothing read", lambda: call(())),
+                ("compress_latents device in, nothing read", lambda: call((), True)),
+                ("compress_latents NumPy in, all three read", lambda: call(("Z_hat", "raw_num_bits", "num_bits"))),
+                ("compress_latents device in, all three read", lambda: call(("Z_hat", "raw_num_bits", "num_bits"), True)),
+                ("compress_latents NumPy in, num_bits read", lambda: call(("num_bits",))),
+                ("compress_latents device in, num_bits read", lambda: call(("num_bits",), True)),
+                ("eager r4 landing alone (again)", v_eager_r4)):
+    print(f"{name:45s} {timeit(f):7.3f} ms")

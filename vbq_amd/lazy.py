@@ -20,6 +20,8 @@ quantizer object), like the staging blocks before.
 from __future__ import annotations
 
 import itertools
+import sys
+import weakref
 from typing import Dict, Optional
 
 import numpy as np
@@ -49,7 +51,8 @@ class HostStager:
         self._pool = None
         self.transfers = 0                       # device-to-host copies issued (tests read it)
         self.bytes = 0
-        self._group = None                       # the call whose results are being read, what was read of it ...
+        self.spare: Dict[str, list] = {}         # host arrays of results nobody holds any more (DeviceStack.__del__): see land()
+        self._group = None                       # (id of) the call whose results are being read, what was read of it ...
         self._reads = set()
         self._prev_reads = set()                 # ... and what was read of the call before: what to prefetch
 
@@ -80,9 +83,23 @@ class HostStager:
         self.transfers += 1
         self.bytes += t.numel() * t.element_size()
 
+        # The array the caller gets is an ordinary pageable one.  A FRESH 25 MB array costs 1.8-2.2 ms to fill (6 400 page faults;
+        # measured: the copy itself is a quarter of that), so arrays of earlier results that nobody references any more are
+        # kept (one per quantity) and filled again: an evaluation loop drops image i's results before it reads image i + 1's.
+        spare = self.spare.get(stack.name)
+        out = None
+        while spare:
+            cand = spare.pop()
+            if cand.shape == tuple(t.shape) and cand.dtype == _NP_DTYPES.get(t.dtype):
+                out = cand
+                break
+
         def land():
             ev.synchronize()
-            return np.array(hv.numpy())          # a fresh pageable array; the block is free again afterwards
+            if out is None:
+                return np.array(hv.numpy())      # a fresh array; the block is free again afterwards
+            np.copyto(out, hv.numpy())
+            return out
         if t.numel() * t.element_size() >= _THREADED_FROM:
             stack._future = self.busy[stack.name] = self.pool().submit(land)
         else:
@@ -90,14 +107,15 @@ class HostStager:
 
     def fetch(self, stack: "DeviceStack") -> np.ndarray:
         """The host copy of `stack`; on the way the transfers of those siblings the PREVIOUS call's results were read for."""
-        if self._group is not stack.siblings:    # the first read of another call's results: remember what the last one was read for
+        if self._group != stack.group:           # the first read of another call's results: remember what the last one was read for
             if self._group is not None:
                 self._prev_reads = self._reads
-            self._group, self._reads = stack.siblings, set()
+            self._group, self._reads = stack.group, set()
         self._reads.add(stack.name)
         self.start(stack)
-        for sib in stack.siblings:
-            if sib is not stack and sib.name in self._prev_reads:
+        for ref in stack.siblings:
+            sib = ref()
+            if sib is not None and sib is not stack and sib.name in self._prev_reads:
                 self.start(sib)
         out, stack._future = stack._future.result(), None
         return out
@@ -117,7 +135,8 @@ class DeviceStack:
     def __init__(self, name: str, tensor: torch.Tensor, stager: Optional[HostStager]):
         self.name, self.tensor, self.stager = name, tensor, stager
         self.id = next(_ids)
-        self.siblings = [self]
+        self.group = self.id                     # the call it belongs to (see group()); siblings: weak references, no cycles --
+        self.siblings = ()                       # a dropped result frees its device tensors and host arrays at once
         self._host = None
         self._future = None                      # a transfer under way (HostStager.start)
         # the stream the producing kernels were enqueued on (its raw handle): a copy issued from another stream waits for it
@@ -139,12 +158,27 @@ class DeviceStack:
     def rows(self):
         return [LazyArray(self, i) for i in range(self.tensor.shape[0])]
 
+    def __del__(self):
+        # Hand the host array back for the next call's results -- only when nobody else can see it: every view a caller took
+        # (np.asarray(lazy) is one) holds a reference to it, so a count of exactly two (the attribute and getrefcount's own
+        # argument) means this object was the last owner.
+        try:
+            st = self.stager
+            if (self._host is not None and st is not None and self._host.nbytes >= _THREADED_FROM and self._host.flags.owndata
+                    and sys.getrefcount(self._host) == 2):
+                keep = st.spare.setdefault(self.name, [])
+                if len(keep) < 1:
+                    keep.append(self._host)
+        except Exception:                        # interpreter shutdown
+            pass
+
 
 def group(stacks):
     """Quantities of ONE call: the first host access of any of them starts the transfers of the others as well."""
     stacks = [s for s in stacks if s is not None]
+    refs = tuple(weakref.ref(s) for s in stacks)
     for s in stacks:
-        s.siblings = stacks
+        s.siblings, s.group = refs, stacks[0].id
     return stacks
 
 
