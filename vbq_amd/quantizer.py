@@ -401,12 +401,12 @@ class ChannelwisePriorCDFQuantizer:
         lambs = list(lambs)
         mu, sg = self._batch_dev(batch_means, batch_stds)
         zhat, bits, _ = self._latents_call(mu, sg, lambs, spread="sigma", level_len=self._level_len_dev(lambs), models=None)
-        Z_hat_dict, num_bits_dict = {}, {}
-        for i, lamb in enumerate(lambs):
-            z, b = zhat[i], bits[i]                                                  # B x C
-            Z_hat_dict[lamb] = z.cpu().numpy() if return_np else z
-            num_bits_dict[lamb] = b.cpu().numpy() if return_np else b
-        return Z_hat_dict, num_bits_dict
+        if return_np:
+            # ndarray-like views over the device tensors (vbq_amd.lazy): what is read on the host crosses PCIe, nothing else
+            from .lazy import DeviceStack, group
+            zs, bs = group([DeviceStack("batch_Z_hat", zhat, self._stager()), DeviceStack("batch_num_bits", bits, self._stager())])
+            return dict(zip(lambs, zs.rows())), dict(zip(lambs, bs.rows()))
+        return {lamb: zhat[i] for i, lamb in enumerate(lambs)}, {lamb: bits[i] for i, lamb in enumerate(lambs)}
 
     # ------------------------------------------------------------------ entropy models (quantizer.py:82-150)
     def _encode(self, X, vae):
