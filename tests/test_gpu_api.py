@@ -965,6 +965,11 @@ def test_per_image_results_stay_on_the_device_until_read(golden):
     assert isinstance(z0, LazyArray) and z0.on_device and z0.shape == means.shape and z0.dtype == np.float32
     assert vae.decoded_from.shape == (16,) + means.shape[1:] and vae.decoded_from.data_ptr() == z0.tensor.data_ptr()
     assert out["X_hat"][lambs[3]].shape == X.shape and out["X_hat"][lambs[3]].on_device
+    # zero-copy hand-over to device libraries (no transfer): the CUDA array interface and DLPack of the tensor behind the view
+    zt = torch.as_tensor(z0, device="cuda")
+    zd = torch.from_dlpack(out["num_bits"][lambs[1]])
+    assert zt.data_ptr() == z0.tensor.data_ptr() and tuple(zt.shape) == z0.shape and zd.data_ptr() == out["num_bits"][lambs[1]].tensor.data_ptr()
+    assert stager.transfers == 0 and z0.on_device
     # the evaluation loop's reads: sums on the device == np.sum of the host arrays, bit for bit
     sums = utils._sums_per_setting(out["num_bits"], lambs)
     sums_cl = utils._sums_per_setting(out["num_bits_cl"], lambs)

@@ -220,6 +220,20 @@ class LazyArray(NDArrayOperatorsMixin):
     def on_device(self) -> bool:
         return self._stack.on_device
 
+    # zero-copy hand-over to device libraries: torch.as_tensor(x, device="cuda"), torch.from_dlpack(x), CuPy, Numba
+    @property
+    def __cuda_array_interface__(self):
+        t = self.tensor
+        if not t.is_cuda:
+            raise AttributeError("__cuda_array_interface__")
+        return t.__cuda_array_interface__
+
+    def __dlpack__(self, *args, **kwargs):
+        return self.tensor.__dlpack__(*args, **kwargs)
+
+    def __dlpack_device__(self):
+        return self.tensor.__dlpack_device__()
+
     @property
     def shape(self):
         return tuple(self._stack.tensor.shape[1:])
