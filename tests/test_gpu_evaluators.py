@@ -222,3 +222,20 @@ def test_evaluate_compression_jpg(tmp_path):
     buf = BytesIO()
     Image.open(p).convert("RGB").save(buf, "jpeg", quality=40)
     assert res["BPP"][1] == buf.tell() * 8 / (96 * 128)
+
+
+def test_unit_to_u8_is_numpys_round_clip_cast():
+    """vbq_unit_to_u8_f32 == np.clip(np.round(x * 255), 0, 255).astype(np.uint8) (utils.py:555) on values inside and outside [0, 1],
+    exact halves (round half to even), tiny and huge magnitudes."""
+    _need_gpu()
+    import torch
+    from vbq_amd import ops
+    rng = np.random.default_rng(3)
+    x = np.concatenate([rng.uniform(-0.2, 1.2, 200_001).astype(np.float32),
+                        ((np.arange(-3, 260, dtype=np.float32) + np.float32(0.5)) / np.float32(255)),
+                        (np.arange(0, 256, dtype=np.float32) / np.float32(255)),
+                        np.float32([0.0, -0.0, 1.0, 1e-30, -1e-30, 1e30, -1e30, 0.0019607844, 0.99803925])])
+    want = np.clip(np.round(x * 255), 0, 255).astype(np.uint8)
+    got = ops.unit_to_u8(torch.from_numpy(x).cuda()).cpu().numpy()
+    assert got.dtype == np.uint8 and np.array_equal(got, want)
+    assert ops.unit_to_u8(torch.zeros((0, 3), device="cuda")).shape == (0, 3)
