@@ -263,6 +263,8 @@ class LazyArray(NDArrayOperatorsMixin):
     def __array__(self, dtype=None, copy=None):
         a = self._stack.host()[self._i, ...]             # (the Ellipsis keeps a 0-d row an array, a view as well)
         if dtype is not None and np.dtype(dtype) != a.dtype:
+            if copy is False:                    # NumPy 2's protocol: a conversion is a copy
+                raise ValueError("a copy is needed to convert the dtype, and copy=False was asked for")
             return a.astype(dtype)
         return a.copy() if copy else a
 
