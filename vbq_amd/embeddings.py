@@ -26,8 +26,22 @@ def _device():
 
 
 def _dev(a, dtype=torch.float32):
-    t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(a)))
+    from .lazy import device_tensor
+    t = device_tensor(a)                     # a result of this package that still lives on the device: no round trip
+    if t is None:
+        t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(a)))
     return t.to(_device(), dtype).contiguous()
+
+
+_STAGER = None
+
+
+def _stager():
+    global _STAGER
+    if _STAGER is None:
+        from .lazy import HostStager
+        _STAGER = HostStager()
+    return _STAGER
 
 
 def empirical_std(vecs, exact: bool = True) -> np.float32:
@@ -65,7 +79,9 @@ def compress_coordinates_sweep(means, stds, betas: Sequence[float], codepoints, 
 def compress_coordinates(means, stds, beta, bitlengths=None, codepoints=None):
     """ipynb:429-443.  `codepoints` replaces the notebook's global of the same name; `bitlengths`
     must be the level of every slot (the only table the notebook ever passes) and is validated.
-    Returns the quantized array (f32, shaped like `means`; NumPy in -> NumPy out)."""
+    Returns the quantized array (f32, shaped like `means`).  Torch in -> a device tensor; NumPy in -> an ndarray-like lazy view
+    (vbq_amd.lazy): the notebook hands the result straight to prediction_ranks / empirical_entropy (ipynb:466-470), which
+    take it on the device -- the 40 MB of a 100000 x 100 vocabulary cross PCIe only if somebody reads them on the host."""
     if codepoints is None:
         raise ValueError("pass codepoints=... (the notebook reads a global; make_code_book() builds it)")
     N = int(np.log2(len(codepoints) + 1)) - 1
@@ -74,8 +90,10 @@ def compress_coordinates(means, stds, beta, bitlengths=None, codepoints=None):
         if not np.array_equal(np.asarray(bitlengths), want):
             raise ValueError("bitlengths must equal the bit level of each level-major slot")
     _, val = compress_coordinates_sweep(means, stds, [beta], codepoints)
-    out = val[0]
-    return out if isinstance(means, torch.Tensor) else out.cpu().numpy()
+    if isinstance(means, torch.Tensor):
+        return val[0]
+    from .lazy import DeviceStack
+    return DeviceStack("coordinates", val, _stager()).rows()[0]
 
 
 def entropy_from_counts(counts) -> float:
