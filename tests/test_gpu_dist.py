@@ -394,7 +394,7 @@ def _host_stage_data():
 
 def _host_stage_build(mu, sg, tab, steps, **kw):
     from vbq_amd.pipeline import EntropyModelBuild
-    dev = torch.device("cuda", 0)
+    dev = torch.device("cuda", torch.cuda.current_device())
     mu_d, sg_d = torch.from_numpy(mu).to(dev).reshape(1, -1), torch.from_numpy(sg).to(dev).reshape(1, -1)
     b = EntropyModelBuild(mu.size, 1, HS_LAMBS, torch.from_numpy(tab).to(dev), N=N, add_n_smoothing=1, **kw)
     assert b.has_host_stages and b.lut1 is None and b.lut2 is None, "the test must take the host-stage route"
@@ -408,13 +408,18 @@ def _host_stage_build(mu, sg, tab, steps, **kw):
             b.counts.cpu().numpy().astype(np.int64), models.cpu().numpy())
 
 
-def _host_stage_worker(rank, world, port, out):
+def _host_stage_worker(rank, world, port, out, backend="gloo"):
     sys.path.insert(0, ROOT)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch.distributed as dist
     from vbq_amd import dist as vd
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    torch.cuda.set_device(0)
+    if backend == "nccl":                                      # real GPUs, RCCL (tests/test_zz_multi_gpu.py)
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        torch.cuda.set_device(0)
     mu, sg, tab = _host_stage_data()
     a, b = vd.shard_rows(HS_ROWS, rank, world)
     res = _host_stage_build(mu[a:b], sg[a:b], tab, 3, global_rows=HS_ROWS, distributed=True, group=dist.group.WORLD,

@@ -12,7 +12,8 @@ import pytest
 torch = pytest.importorskip("torch")
 import torch.multiprocessing as mp
 
-from test_gpu_dist import LAMBS, N, ROOT, _build, _data, _run_cabi_comm
+from test_gpu_dist import (HS_ROWS, LAMBS, N, ROOT, _build, _data, _host_stage_build, _host_stage_data, _host_stage_worker,
+                           _run_cabi_comm)
 
 pytestmark = pytest.mark.gpu
 
@@ -108,3 +109,31 @@ def test_two_rank_rccl_build_equals_single_process():
     assert np.array_equal(res[0]["pipe_levels"], res[1]["pipe_levels"]) and res[0]["pipe_levels"].sum() == len(LAMBS) * mu.size
 
 
+
+
+@pytest.mark.timeout(900)
+def test_two_rank_rccl_build_through_the_host_stage():
+    """The large C = 1 configurations of the 8-GPU run (2^24 rows per histogram row or more: the -log2 steps as a stream-ordered
+    host function beside the asynchronous, double-buffered RCCL all-reduces) on two real GPUs: every rank ends with the tables one
+    process computes from all rows.  (On one GPU: tests/test_gpu_dist.py runs the same build over gloo.)"""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (runs on the driver's 8-GPU node)")
+    import torch.distributed as dist
+    if not dist.is_nccl_available():
+        pytest.skip("torch.distributed was built without the nccl (RCCL) backend")
+    mu, sg, tab = _host_stage_data()
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = 29700 + os.getpid() % 100
+    procs = [ctx.Process(target=_host_stage_worker, args=(r, 2, port, out, "nccl")) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(out.get(timeout=700) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    ref = _host_stage_build(mu, sg, tab, 2)                        # the parent touches the GPU only after the children are done
+    assert int(ref[0].sum()) == 2 * HS_ROWS
+    for r in range(2):
+        for got, want, what in zip(res[r], ref, ("level_counts", "level_len", "raw_models", "counts", "models")):
+            assert np.array_equal(got, want), (r, what)
