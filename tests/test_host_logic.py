@@ -433,3 +433,19 @@ def test_lazy_results_recycle_only_arrays_nobody_holds():
         assert len(st.spare["q"]) == 1                        # one spare per quantity is enough for a loop
     finally:
         LZ._THREADED_FROM = old
+
+
+def test_evaluation_reads_on_plain_numpy_results():
+    """utils.evaluation_reads (what the evaluation loop reads from one compress() result, utils.py:547-556) on the reference's own
+    form -- dicts of NumPy arrays, no device anywhere: np.sum of the first image per setting, uint8 reconstructions."""
+    rng = np.random.default_rng(2)
+    settings = [0.1, 1.0, 10.0]
+    nb = {l: rng.gamma(2.0, 2.0, (1, 4, 6, 5)).astype(np.float32) for l in settings}
+    cl = {l: rng.gamma(2.0, 1.0, (1, 4, 6, 5)).astype(np.float32) for l in settings}
+    xh = {l: rng.uniform(-0.1, 1.1, (1, 16, 24, 3)).astype(np.float32) for l in settings}
+    sums, sums_cl, u8 = utils.evaluation_reads({"num_bits": nb, "num_bits_cl": cl, "X_hat": xh}, settings)
+    assert [s for s in sums] == [np.sum(nb[l][0]) for l in settings] and [s for s in sums_cl] == [np.sum(cl[l][0]) for l in settings]
+    assert u8.dtype == np.uint8 and u8.shape == (3, 16, 24, 3)
+    assert np.array_equal(u8[1], np.clip(np.round(xh[1.0][0] * 255), 0, 255).astype(np.uint8))
+    sums2, sums_cl2, _ = utils.evaluation_reads({"num_bits": nb, "X_hat": xh}, settings)        # no 'num_bits_cl': falls back to num_bits
+    assert np.array_equal(sums2, sums) and np.array_equal(sums_cl2, sums)
