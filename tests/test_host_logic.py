@@ -403,6 +403,49 @@ def test_native_host_stage_arithmetic_is_numpys():
     assert d.status == -1 and d.runs == 1
 
 
+def test_ufunc_struct_is_never_read_on_an_unknown_object_layout(monkeypatch):
+    """pipeline.numpy_log2_f32_loop lays a hand-declared PyUFuncObject over id(np.log2); on another object layout the first
+    field read would be a segmentation fault, not an exception.  Every guard -- interpreter, free-threaded / trace-refs builds,
+    pointer width, NumPy version range, the ufunc's type, its ob_type word -- answers "do not read" on its own, BEFORE
+    `from_address`; the builds then keep the Python host stage (None)."""
+    import sys
+    import sysconfig
+    import types
+    import vbq_amd.pipeline as P
+
+    class Tripwire:
+        @staticmethod
+        def from_address(_):
+            raise AssertionError("the ufunc object was dereferenced although a guard said no")
+
+    def loop_with(patch):
+        monkeypatch.setattr(P, "_LOG2_LOOP", None)
+        monkeypatch.setattr(P, "_PyUFuncObject", Tripwire)
+        patch()
+        try:
+            assert P._ufunc_struct_is_readable() is False
+            assert P.numpy_log2_f32_loop() is None
+        finally:
+            monkeypatch.undo()
+
+    assert P._ufunc_struct_is_readable() is True                          # this interpreter / NumPy: the fast stage is in use
+    loop_with(lambda: monkeypatch.setattr(sys, "implementation", types.SimpleNamespace(name="pypy")))
+    real_cfg = sysconfig.get_config_var
+    loop_with(lambda: monkeypatch.setattr(sysconfig, "get_config_var", lambda k: 1 if k == "Py_GIL_DISABLED" else real_cfg(k)))
+    loop_with(lambda: monkeypatch.setattr(sysconfig, "get_config_var", lambda k: 1 if k == "Py_TRACE_REFS" else real_cfg(k)))
+    loop_with(lambda: monkeypatch.setattr(sys, "getobjects", lambda *a: [], raising=False))
+    loop_with(lambda: monkeypatch.setattr(P._C, "sizeof", lambda t: 4))
+    loop_with(lambda: monkeypatch.setattr(np, "__version__", "1.17.4"))
+    loop_with(lambda: monkeypatch.setattr(np, "__version__", "3.0.0"))
+    loop_with(lambda: monkeypatch.setattr(np, "__version__", "not a version"))
+    loop_with(lambda: monkeypatch.setattr(np, "log2", lambda x: x))       # a wrapper, not the ufunc object
+    loop_with(lambda: monkeypatch.setattr(P, "_NUMPY_TESTED", ("9.0.0", "9.1.0")))
+    # after all of that the real answer is unchanged, and it is the loop the arithmetic test accepts
+    monkeypatch.setattr(P, "_LOG2_LOOP", None)
+    loop = P.numpy_log2_f32_loop()
+    assert loop is not None and loop[0]
+
+
 def test_lazy_results_recycle_only_arrays_nobody_holds():
     """HostStager keeps the host array of a dropped result for the next call's -- but only when no view of it is alive anywhere
     (every np.asarray(lazy) is a view and holds a reference)."""

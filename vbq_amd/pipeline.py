@@ -110,21 +110,52 @@ class _PyUFuncObject(_C.Structure):
 
 
 _LOG2_LOOP = None          # (function pointer, data pointer) of np.log2's float32 inner loop; False: not usable here
+_NUMPY_TESTED = ("1.21.0", "2.4.0")      # [first, last) NumPy versions whose PyUFuncObject head is the struct above
+
+
+def _ufunc_struct_is_readable():
+    """May `_PyUFuncObject` be laid over `id(np.log2)`?  Every condition is checked BEFORE the first dereference: on another
+    object layout (free-threaded CPython: a wider PyObject_HEAD; Py_TRACE_REFS builds; another interpreter; a NumPy outside the
+    range this was read against) the `name` / `types` / `functions[i]` reads would be a segmentation fault, which the
+    `try / except` around them cannot catch.  Anything unexpected answers False and the callers keep the Python stage."""
+    import sys
+    import sysconfig
+    if sys.implementation.name != "cpython":
+        return False
+    if sysconfig.get_config_var("Py_GIL_DISABLED") or sysconfig.get_config_var("Py_TRACE_REFS") or hasattr(sys, "getobjects"):
+        return False
+    if _C.sizeof(_C.c_ssize_t) != 8 or _C.sizeof(_C.c_void_p) != 8:
+        return False
+    try:
+        v = np.lib.NumpyVersion(np.__version__)
+        if not (v >= _NUMPY_TESTED[0] and v < _NUMPY_TESTED[1]):
+            return False
+    except Exception:
+        return False
+    if type(np.log2) is not np.ufunc:
+        return False
+    # the object header as this interpreter lays it out: ob_type at offset 8 must be the ufunc type itself
+    if _C.c_void_p.from_address(id(np.log2) + 8).value != id(np.ufunc):
+        return False
+    return object.__basicsize__ == 16 and np.ufunc.__basicsize__ >= _C.sizeof(_PyUFuncObject)
 
 
 def numpy_log2_f32_loop():
     """NumPy's own float32 log2 as a C function pointer (the first float32 -> float32 inner loop of the np.log2 ufunc object:
     the one NumPy's type resolution picks), so that a host function WITHOUT the interpreter lock can produce the reference's
-    numbers -- NumPy's float32 log2 is neither libm's nor correctly rounded.  Trusted only after the library's host routine,
+    numbers -- NumPy's float32 log2 is neither libm's nor correctly rounded.  The ufunc object is only read where
+    `_ufunc_struct_is_readable()` vouches for its layout, and the pointer is trusted only after the library's host routine,
     driven by it, has reproduced entropy.neg_log2_freq bit for bit on a random table; None otherwise (the callers then keep the
     Python stage)."""
     global _LOG2_LOOP
     if _LOG2_LOOP is None:
         _LOG2_LOOP = False
         try:
+            if not _ufunc_struct_is_readable():
+                return None
             u = _PyUFuncObject.from_address(id(np.log2))
             NPY_FLOAT = 11
-            if u.name == b"log2" and u.nin == 1 and u.nout == 1 and u.nargs == 2 and 0 < u.ntypes < 64 and u.functions and u.types:
+            if u.nin == 1 and u.nout == 1 and u.nargs == 2 and 0 < u.ntypes < 64 and u.functions and u.types and u.name == b"log2":
                 for i in range(u.ntypes):
                     if ord(u.types[2 * i]) == NPY_FLOAT and ord(u.types[2 * i + 1]) == NPY_FLOAT and u.functions[i]:
                         cand = (int(u.functions[i]), int((u.data[i] if u.data else 0) or 0))
