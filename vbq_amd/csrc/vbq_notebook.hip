@@ -539,7 +539,9 @@ __device__ __forceinline__ void nb_thresholds(const float (&dv)[11], float (&Tn)
 // CW: words of eight 4-bit fields per column (positions 0 .. L: 5 for L <= 32, 9 for L <= 64).  NF > 0: the sweep has exactly NF full
 // words (L >> 3 == NF) and they are emitted as ONE straight block -- all 16 NF rank reads of a lane pair in flight together --
 // instead of NF blocks with a branch and a full LDS latency each; a last partial word takes the generic code.
-template <bool WITH_VAL, int CW, int NF>
+// BUF: all index rows lie within 4 GB of out_idx (the host checks): the straight block's stores go through one buffer descriptor
+// with the row's byte offset as the instruction's scalar offset (no 64-bit address arithmetic per store).
+template <bool WITH_VAL, int CW, int NF, bool BUF>
 __global__ void __launch_bounds__(256, WITH_VAL ? 2 : (CW <= 5 ? 4 : 3))
 k_quant_notebook_hull(const float *__restrict__ means, const float *__restrict__ stds, long n,
                       const double *__restrict__ codebook, NbSweep sw, uint16_t *__restrict__ out_idx,
@@ -747,8 +749,13 @@ k_quant_notebook_hull(const float *__restrict__ means, const float *__restrict__
 #pragma unroll
                     for (int k = 0; k < NE; ++k) {
                         P[wd][k] = (cw[wd][k] + run[k]) * 0x11111111u;
+                        // opaque: the compiler otherwise folds every LEFT shift of P below into a multiplication of its own
+                        // (v_mul_lo_u32, quarter rate): 6 NF of them per iteration instead of 2 NF
+                        asm volatile("" : "+v"(P[wd][k]));
                         run[k] = P[wd][k] >> 28;
                     }
+                const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(out_idx, 0, -1 /* 4 GB */, 0x00020000);
+                const uint32_t voff2 = (uint32_t)(2 * i0), row_bytes = (uint32_t)(2 * n);
 #pragma unroll
                 for (int half = 0; half < NF / 2; ++half) {
                     uint32_t v[16], pw4[4];
@@ -770,7 +777,8 @@ k_quant_notebook_hull(const float *__restrict__ means, const float *__restrict__
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
                         const uint32_t rowi = (pw4[i >> 2] >> (8 * (i & 3))) & 0xffu;
-                        __builtin_nontemporal_store(v[i], reinterpret_cast<uint32_t *>(oi + (long)rowi * n));
+                        if constexpr (BUF) __builtin_amdgcn_raw_buffer_store_b32(v[i], orsrc, voff2, rowi * row_bytes, 2 /* nt */);
+                        else __builtin_nontemporal_store(v[i], reinterpret_cast<uint32_t *>(oi + (long)rowi * n));
                     }
                 }
             }
@@ -910,17 +918,18 @@ int launch_notebook_hull10(const float *means, const float *stds, int64_t n, con
     const int64_t cap = (int64_t)num_cus() * (ov ? 2 : (Lc <= 32 ? 4 : 3)) * rounds;              // persistent grid: every CU's resident workgroups, two rounds
     if (gx > cap) gx = cap;
     if (gx < 1) gx = 1;
-#define VBQ_NB_HULL(V, W, F)                                                                                          \
-    hipLaunchKernelGGL((k_quant_notebook_hull<V, W, F>), dim3((unsigned)gx), dim3(256), 0, st, means, stds, (long)n, codebook, sw, oi, \
+#define VBQ_NB_HULL(V, W, F, B)                                                                                       \
+    hipLaunchKernelGGL((k_quant_notebook_hull<V, W, F, B>), dim3((unsigned)gx), dim3(256), 0, st, means, stds, (long)n, codebook, sw, oi, \
                        ov, vec_ok, dbg)
+    const bool buf = (uint64_t)Lc * 2ull * (uint64_t)n <= 0xffffffffull;       // every index row within 4 GB of the first
     if (ov) {
-        if (Lc <= 32) VBQ_NB_HULL(true, 5, 0); else VBQ_NB_HULL(true, 9, 0);
+        if (Lc <= 32) VBQ_NB_HULL(true, 5, 0, false); else VBQ_NB_HULL(true, 9, 0, false);
     } else if (Lc == 32) {                                   // 32 betas: four full words in one straight block
-        VBQ_NB_HULL(false, 5, 4);
+        if (buf) VBQ_NB_HULL(false, 5, 4, true); else VBQ_NB_HULL(false, 5, 4, false);
     } else if ((Lc >> 3) == 6) {                             // 48 .. 55 betas (the notebook's 50): six
-        VBQ_NB_HULL(false, 9, 6);
+        if (buf) VBQ_NB_HULL(false, 9, 6, true); else VBQ_NB_HULL(false, 9, 6, false);
     } else {
-        if (Lc <= 32) VBQ_NB_HULL(false, 5, 0); else VBQ_NB_HULL(false, 9, 0);
+        if (Lc <= 32) VBQ_NB_HULL(false, 5, 0, false); else VBQ_NB_HULL(false, 9, 0, false);
     }
 #undef VBQ_NB_HULL
     VBQ_CHECK_LAUNCH("quant_notebook_hull");

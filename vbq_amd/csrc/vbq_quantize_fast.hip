@@ -865,7 +865,7 @@ k_level_counts_hull(const float *__restrict__ mu, const float *__restrict__ sg, 
 #endif
 // LFIX = 32 / 16: the sweep has exactly that many points (four / two full words of the "levels lost" column): the emission is one straight block
 // -- all 64 rank reads of a lane pair in flight together -- instead of four blocks with a branch and a full LDS latency each.
-template <int N, int LFIX>
+template <int N, int LFIX, bool BUF>
 __global__ void __launch_bounds__(256, VBQ_K1E_WAVES)
 k_quant_hull_idx(const float *__restrict__ mu, const float *__restrict__ sg, long n_per_ch, long ch_stride, int C,
                  const float *__restrict__ table, Lambdas32 lam, HullSweep sw, int vec_ok,
@@ -876,7 +876,8 @@ k_quant_hull_idx(const float *__restrict__ mu, const float *__restrict__ sg, lon
     constexpr int PS = (N1 + 3) & ~3;
     constexpr int CW = 5;                                     // words of eight 4-bit fields: sorted positions 0 .. 32
     struct Lds {
-        unsigned short rk[N1 * NE * 256];                     // rank of the better side, [N - level][element][thread]
+        unsigned short rk[N1 * NE * 256];                     // rank of the better side, [N - level][thread][element]: a lane's two
+                                                              // ranks share a dword, so the 32 lanes of an LDS group sit on 32 banks
         float tb[T + 1];
         float penl[kMaxLambdaChunk * PS];                     // fl32(lambda) * n in the caller's order (literal scan only)
         unsigned char lut[kHullKeys];
@@ -916,6 +917,9 @@ k_quant_hull_idx(const float *__restrict__ mu, const float *__restrict__ sg, lon
     const char *tbb = reinterpret_cast<const char *>(tb);
     const unsigned int lane = tid & 63u;
 
+    // BUF: every index plane starts within 4 GB of out_idx (the host checks): stores address them through one buffer descriptor
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(out_idx, 0, -1 /* 4 GB */, 0x00020000);
+    const uint32_t plane_bytes = (uint32_t)(2 * E);
     unsigned int rot = wave_slot();
     for (long q = (long)blockIdx.x * blockDim.x + tid; q < npairs; q += (long)gridDim.x * blockDim.x) {
         rotate_issue_priority(rot);                            // resident grid: see vbq_common.h
@@ -978,7 +982,7 @@ k_quant_hull_idx(const float *__restrict__ mu, const float *__restrict__ sg, lon
                     g[k] = 2 * g[k] + (below ? 4u : 0u);
                     const uint32_t b4 = r_better ? hi4 : lo4;
                     const uint32_t better = n < N ? (b4 << (N - n - 1)) + ((1u << (N - n)) - 1u) : (b4 >> 1);
-                    rk[((N - n) * NE + k) * 256 + tid] = (unsigned short)better;
+                    rk[(((N - n) * 256 + tid) * NE) + k] = (unsigned short)better;
                     if (n >= 1) {
                         const float bound = __fmul_rn(fmaf((float)n, du[k][n - 1], du[k][n]), 1.9073486328125e-06f);
                         tiny[k] |= (r_better && !(__fsub_rn(dL, dR) > bound)) ? (1u << n) : 0u;
@@ -1080,7 +1084,7 @@ k_quant_hull_idx(const float *__restrict__ mu, const float *__restrict__ sg, lon
             const char *rkb = reinterpret_cast<const char *>(rk);
             uint32_t lbase[NE], run[NE] = {0, 0};
 #pragma unroll
-            for (int k = 0; k < NE; ++k) lbase[k] = (k * 256 + tid) * 2;           // bits 0 .. 9; the level index goes into bits 10 .. 13
+            for (int k = 0; k < NE; ++k) lbase[k] = (tid * NE + k) * 2;           // bits 0 .. 9; the level index goes into bits 10 .. 13
             const int nfull = L >> 3;
             if constexpr (LFIX == 32 || LFIX == 16) {
                 constexpr int NFW = LFIX / 8;                              // full words
@@ -1093,6 +1097,9 @@ k_quant_hull_idx(const float *__restrict__ mu, const float *__restrict__ sg, lon
 #pragma unroll
                     for (int k = 0; k < NE; ++k) {
                         P[wd][k] = (cw[wd][k] + run[k]) * 0x11111111u;
+                        // opaque: the compiler otherwise folds every LEFT shift of P below into a multiplication of its own
+                        // (v_mul_lo_u32 by 0x440 / 0x444: quarter rate) -- 24 of them per iteration instead of 8
+                        asm volatile("" : "+v"(P[wd][k]));
                         run[k] = P[wd][k] >> 28;
                     }
 #pragma unroll
@@ -1117,8 +1124,14 @@ k_quant_hull_idx(const float *__restrict__ mu, const float *__restrict__ sg, lon
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
                         const uint32_t plane = (pw[i >> 2] >> (8 * (i & 3))) & 0xffu;
-                        const uint16_t *pl = out_idx + (long)plane * E;              // uniform: a scalar register pair
-                        asm volatile("global_store_dword %0, %1, %2 nt" : : "v"(voff2), "v"(v[i]), "s"(pl) : "memory");
+                        if constexpr (BUF) {
+                            // all planes within 4 GB of out_idx: one buffer descriptor, the plane's byte offset as the
+                            // instruction's SCALAR offset -- two scalar instructions per store instead of eight
+                            __builtin_amdgcn_raw_buffer_store_b32(v[i], orsrc, voff2, plane * plane_bytes, 2 /* nt */);
+                        } else {
+                            const uint16_t *pl = out_idx + (long)plane * E;          // uniform: a scalar register pair
+                            asm volatile("global_store_dword %0, %1, %2 nt" : : "v"(voff2), "v"(v[i]), "s"(pl) : "memory");
+                        }
                     }
                 }
             } else
@@ -1178,7 +1191,7 @@ k_quant_hull_idx(const float *__restrict__ mu, const float *__restrict__ sg, lon
 #pragma unroll
                     for (int wd = 0; wd < CW - 1; ++wd) w = (l >> 3) == wd ? cw[wd][k] : w;
                     r[k] += (w >> (4 * (l & 7))) & 15u;
-                    if (i0 + k < n_per_ch) oi[(long)sw.perm[l] * E + k] = rk[(r[k] * NE + k) * 256 + tid];
+                    if (i0 + k < n_per_ch) oi[(long)sw.perm[l] * E + k] = rk[(r[k] * 256 + tid) * NE + k];
                 }
             }
         }
@@ -1604,15 +1617,15 @@ int launch_quant_hull_idx10(const float *mu, const float *sg, int64_t n_per_ch, 
     static const int dbg = [] { const char *e = getenv("VBQ_FAST_DEBUG"); return e ? atoi(e) : 0; }();
     Lambdas32 l32;
     for (int i = 0; i < kMaxLambdaChunk; ++i) l32.lam[i] = i < L ? (float)lam[i] : 0.0f;
-    if (L == 32)
-        hipLaunchKernelGGL((k_quant_hull_idx<10, 32>), dim3((unsigned)gx, (unsigned)n_ch), dim3(256), 0, st, mu, sg, (long)n_per_ch,
-                           (long)ch_stride, (int)n_ch, table, l32, sw, vec_ok, out_idx, (long)E, dbg);
-    else if (L == 16)                                        // the sweep of post_process.py:115
-        hipLaunchKernelGGL((k_quant_hull_idx<10, 16>), dim3((unsigned)gx, (unsigned)n_ch), dim3(256), 0, st, mu, sg, (long)n_per_ch,
-                           (long)ch_stride, (int)n_ch, table, l32, sw, vec_ok, out_idx, (long)E, dbg);
-    else
-        hipLaunchKernelGGL((k_quant_hull_idx<10, 0>), dim3((unsigned)gx, (unsigned)n_ch), dim3(256), 0, st, mu, sg, (long)n_per_ch,
-                           (long)ch_stride, (int)n_ch, table, l32, sw, vec_ok, out_idx, (long)E, dbg);
+    // all L planes within 4 GB: the emission addresses them through one buffer descriptor (32-bit scalar plane offsets)
+    const bool buf = (uint64_t)L * 2ull * (uint64_t)E <= 0xffffffffull;
+#define VBQ_K1E_LAUNCH(LF, BF)                                                                                                \
+    hipLaunchKernelGGL((k_quant_hull_idx<10, LF, BF>), dim3((unsigned)gx, (unsigned)n_ch), dim3(256), 0, st, mu, sg,          \
+                       (long)n_per_ch, (long)ch_stride, (int)n_ch, table, l32, sw, vec_ok, out_idx, (long)E, dbg)
+    if (L == 32) { if (buf) VBQ_K1E_LAUNCH(32, true); else VBQ_K1E_LAUNCH(32, false); }
+    else if (L == 16) { if (buf) VBQ_K1E_LAUNCH(16, true); else VBQ_K1E_LAUNCH(16, false); }      // the sweep of post_process.py:115
+    else VBQ_K1E_LAUNCH(0, false);
+#undef VBQ_K1E_LAUNCH
     VBQ_CHECK_LAUNCH("quant_hull_idx");
     return VBQ_OK;
 }
