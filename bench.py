@@ -58,7 +58,43 @@ LAMBDAS = [float(v) for v in 2.0 ** np.linspace(-8, 7.5, 32)]
 LAMBDAS_16 = [float(v) for v in 2.0 ** np.linspace(-8, 7, 16)]          # post_process.py:115
 BETAS_50 = [float(b) for b in np.exp(np.linspace(np.log(0.01), np.log(100000), 50))]      # ipynb cell 32
 HBM_PEAK = 8.0e12
+HBM_COPY_MEASURED = 6.29e12            # float4 copy on MI355X (MI355X_MICROARCH.md)
 XI = np.concatenate([(np.arange(2 ** n) + 0.5) / 2 ** n for n in range(N_BITS + 1)])
+
+# DESIGN.md section 6, "What a SCALE run should show": the prediction table of the headline workload (weak scaling: one
+# Kodak-24 tensor per rank, C = 256, 32 lambdas) under the key names the N > 1 line reports its OBSERVED values with
+# (`scale_check`), so that the first real SCALE record can be diffed against it mechanically.  [lo, hi] ranges; the
+# isolated all-reduce as [all links, one ring].
+SCALE_PREDICTION = {
+    2: {"rank_histogram_payload_bytes": 44.7e6, "allreduce_isolated_ms": [0.84, 0.84], "allreduce_hidden": False,
+        "level_allreduce_exposed_ms": 0.045, "k1t_plus_k1_beside_collective_ms": [0.055, 0.060], "step_ms": [0.88, 0.95],
+        "value": [6.4e11, 6.9e11], "efficiency_vs_n1": [0.68, 0.73]},
+    4: {"rank_histogram_payload_bytes": 44.7e6, "allreduce_isolated_ms": [0.45, 1.26], "allreduce_hidden": True,
+        "level_allreduce_exposed_ms": 0.055, "k1t_plus_k1_beside_collective_ms": [0.055, 0.060], "step_ms": [0.78, 0.84],
+        "value": [1.44e12, 1.55e12], "efficiency_vs_n1": [0.76, 0.82]},
+    8: {"rank_histogram_payload_bytes": 44.7e6, "allreduce_isolated_ms": [0.26, 1.48], "allreduce_hidden": True,
+        "level_allreduce_exposed_ms": 0.070, "k1t_plus_k1_beside_collective_ms": [0.055, 0.060], "step_ms": [0.80, 0.86],
+        "value": [2.8e12, 3.0e12], "efficiency_vs_n1": [0.74, 0.80]},
+}
+
+
+def scale_check(full):
+    """`predicted` (headline workload only) next to `observed` (this run) under the same keys."""
+    ar, per = full.get("allreduce"), full.get("per_gpu")
+    if not ar or not per:
+        return None
+    n = full.get("n_gpus")
+    beside = max((g.get("pass1_k1t_ms") or 0) + (g.get("pass2_k1_ms") or 0) - (g.get("pass1_k1t_ms_without_collectives") or 0)
+                 - (g.get("pass2_k1_ms_without_collectives") or 0) for g in per)
+    iso, step0 = ar.get("rank_histogram_allreduce_ms_isolated"), ar.get("ms_per_step_without_collectives")
+    obs = {"rank_histogram_payload_bytes": ar.get("rank_histogram_payload_bytes"), "allreduce_isolated_ms": _sig(iso, 4),
+           "allreduce_hidden": bool(iso is not None and step0 is not None and iso < step0),
+           "level_allreduce_exposed_ms": _sig(ar.get("exposed_ms_per_step"), 3),
+           "k1t_plus_k1_beside_collective_ms": _sig(beside, 3), "step_ms": _sig(full.get("ms_per_step"), 4),
+           "value": _sig(full.get("value"), 4), "efficiency_vs_n1": None}      # the driver computes efficiency from its own N = 1 run
+    headline_wl = str((full.get("config") or {}).get("workload", "")).startswith("kodak24_c256") and full.get("scaling") == "weak"
+    return {"predicted": SCALE_PREDICTION.get(n) if headline_wl else None, "observed": obs}
+
 
 WORKLOADS = {
     # name: (rows, channels, description)
@@ -298,8 +334,12 @@ def headline(full, side_file=None):
                       "timed_regions_ms_per_step": [_sig(v, 4) for v in (full.get("timed_regions_ms_per_step") or [])]}
     line["roofline"] = {k: _sig(roof.get(k)) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic",
                                                         "algorithmic_bytes_per_launch", "avg_launch_ms", "limited_by",
-                                                        "valu_issue_frac")}
+                                                        "valu_issue_frac", "traffic_source", "frac_of_measured_copy", "ceiling_frac",
+                                                        "step_intermediate_bytes")}
     line["roofline"]["kernel"] = str(roof.get("kernel", "")).split(" ")[0]
+    if roof.get("traffic_source"):                           # "<file> (committed ..., not this run)" -> file + tag
+        line["roofline"]["traffic_source"] = str(roof["traffic_source"]).split(" ")[0] + " (committed pmc, not this run)"
+    line["roofline"]["per_lambda_read_frac"] = [_sig(v, 3) for v in (roof.get("per_lambda_read_frac") or [])] or None
     cb = full.get("cpu_baseline")
     line["cpu_baseline"] = None if not cb else {"value": _sig(cb.get("value")), "unit": cb.get("unit"), "cores": cb.get("cores"),
                                                 "kind": cb.get("kind"), "sample": str(cb.get("sample", ""))[:200]}
@@ -317,6 +357,9 @@ def headline(full, side_file=None):
                              "isolated_ms": _sig(ar.get("rank_histogram_allreduce_ms_isolated"), 4),
                              "ms_per_step_without_collectives": _sig(ar.get("ms_per_step_without_collectives"), 4),
                              "exposed_ms_per_step": _sig(ar.get("exposed_ms_per_step"), 4)}
+    sc = scale_check(full)
+    if sc:                           # DESIGN section 6's prediction and this run, same keys
+        line["scale_check"] = sc
     if full.get("per_gpu"):          # [k1t ms, k1 ms, k2 ms, K1 HBM fraction, k1 ms in the steps without collectives] per rank
         line["per_gpu"] = [[_sig(g.get("pass1_k1t_ms"), 4), _sig(g.get("pass2_k1_ms"), 4), _sig(g.get("pass2_k2_ms"), 4),
                             _sig(g.get("k1_hbm_frac"), 3), _sig(g.get("pass2_k1_ms_without_collectives"), 4)] for g in full["per_gpu"]]
@@ -325,7 +368,7 @@ def headline(full, side_file=None):
                                  v.get("parity_ok", v.get("parity_vs_oracle_on_sample"))] for k, v in full["workloads"].items()}
     line["full_record"] = side_file
     # never let the line outgrow the driver's parser again: shed the optional parts, largest first
-    for drop in ("workloads", "per_gpu", "allreduce", "stages_ms", "stages_frac"):
+    for drop in ("workloads", "per_gpu", "allreduce", "scale_check", "stages_ms", "stages_frac"):
         if len(json.dumps(line)) < LINE_LIMIT:
             break
         line.pop(drop, None)
@@ -548,7 +591,19 @@ def run_workload(name, args, torch, dist, dev, rank, world, steps, warmup, detai
         "solves_per_s_counting_both_passes": 2 * total_E * L * steps / dt,
         "roofline": {"bound": "hbm", "limited_by": "valu issue", "kernel": "k_quant_fast (pass 2: corrected lengths -> rank indices)",
                      "achieved": alg_bytes / (k1_ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                     "frac": alg_bytes / (k1_ms * 1e-3) / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_src,
+                     "frac": alg_bytes / (k1_ms * 1e-3) / HBM_PEAK, "traffic": traffic,
+                     # `traffic` and `valu_issue_frac` are NOT measured in this run: they are the newest committed rocprofv3 --pmc
+                     # passes of this same workload (2 x FETCH_SIZE + WRITE_SIZE per launch), named here
+                     "traffic_source": (traffic_src + " (committed rocprofv3 --pmc passes, not this run)") if traffic_src else None,
+                     # the same achieved rate against the 6.29 TB/s a float4 copy measures on this chip
+                     "frac_of_measured_copy": alg_bytes / (k1_ms * 1e-3) / HBM_COPY_MEASURED,
+                     # what the exact dense argmin can reach with a perfect locate: VALU issue slots, not bytes
+                     "ceiling_frac": 0.35, "ceiling_source": "EXPERIMENTS.md, 'a bound for the dense formulation' (rounds 1-2 text) and 'K1's phase B, costed' (round 5)",
+                     # throughput against the north star's unfused per-lambda ceiling (8 B read per latent): [this kernel, whole step]
+                     "per_lambda_read_frac": [E * L / (k1_ms * 1e-3) / (HBM_PEAK / 8.0), E * L * steps / dt / (HBM_PEAK / 8.0)],
+                     # the index planes K1 writes and K2 reads back: intermediate bytes of the STEP that are in no result
+                     "step_intermediate_bytes": 4 * L * E,
+                     "step_floor_bytes": 16 * E + 8 * L * C * T,
                      "algorithmic_bytes_per_pass": alg_bytes, "launches_per_pass": k1_n,
                      "algorithmic_bytes_per_launch": alg_bytes / max(k1_n, 1), "avg_launch_ms": k1_ms / max(k1_n, 1),
                      "pass_ms": k1_ms, "latents_per_s_kernel_only": E * L / (k1_ms * 1e-3),
@@ -892,6 +947,7 @@ def main():
             others["embeddings_1e7_notebook"] = {k: nb[k] for k in ("ms_per_step", "value", "unit", "roofline", "parity_vs_oracle_on_sample")}
             others["embeddings_1e7_notebook"]["workload"] = nb["config"]["workload"]
             others.update(run_call_patterns(torch, dev))
+            others.update(run_next_rows(torch, dev))
         if rank == 0:
             out["workloads"] = others
     if rank == 0:
@@ -1038,6 +1094,159 @@ def run_call_patterns(torch, dev, steps=10, warmup=3):
                     "parity_vs_oracle_on_sample": bool(ok),
                     "workload": f"embeddings_1e7: {WORKLOADS['embeddings_1e7'][2]}; {what}; notebook arithmetic (f64 squared error, ipynb:429-443), indices out"}
         del ix
+    return out
+
+
+MFMA_F32_PEAK = 157.3e12      # MI355X dense f32 matrix peak (MI355X_MICROARCH.md)
+VALU_F32_PEAK = 157.3e12      # f32 vector peak (256 CUs x 128 FMA lanes x 2 x 2.4 GHz)
+
+
+def run_next_rows(torch, dev, steps=5, warmup=2):
+    """The rows of SURVEY 8(f) and the prior's CDF (K4) under the same clock as the headline -- each with the roofline that bounds
+    it and a parity verdict against its checker (outside the timed region):
+      rans_encode / rans_decode    the entropy coder on the index planes of the Kodak-24 sweep (quantizer.py:144,226-228 made real):
+                                   3.0e8 symbols in 8192 streams; HBM bound on 2 B per symbol + the compressed words
+      prediction_ranks_1e5x100     the analogy evaluator (ipynb:199-209): 19544 questions x 100000 words x 100 dims, fused f32-MFMA
+                                   GEMM + rank count; bound "mfma" against the dense f32 matrix peak
+      ms_ssim_kodak                MS-SSIM (img_comparison_metrics.py:160) of one 512 x 768 RGB image against 16 reconstructions
+      bmshj_icdf_table_c256        BMSHJ2018Prior.inverse_cdf on the [2047, 256] xi grid (learned_prior.py:173-218): the code-point
+                                   table of build_code_points; f32 vector arithmetic (parity: NumPy restatement, UNPINNED)
+      bmshj_fit_pass               one NLL + gradient pass of the prior fit (learned_prior.py:363-462) over 500 x 1536 x 256 latents"""
+    from vbq_amd import embeddings as Emb, metrics as Mx, ops, priors
+    from vbq_amd.coder import RansCodec, ideal_bits, quantize_frequencies
+    from oracle import c_oracle as CO, vbq_oracle as O
+    out = {}
+    th = CO.max_threads()
+
+    def entry(ms, bound, achieved, peak, roof_unit, kernel, ok, what, **extra):
+        d = {"ms_per_step": ms, "roofline": {"bound": bound, "kernel": kernel, "achieved": achieved, "peak": peak, "unit": roof_unit,
+                                             "frac": achieved / peak, "avg_launch_ms": ms},
+             "parity_vs_oracle_on_sample": bool(ok), "workload": what}
+        d.update(extra)
+        return d
+
+    # ---- rANS on the Kodak-24 sweep's indices
+    rows, C, _ = WORKLOADS["kodak24_c256"]
+    L = len(LAMBDAS)
+    mu_h, sg_h, tab_h = make_inputs_with_table(rows, C, 1000)
+    mu, sg = (torch.from_numpy(np.ascontiguousarray(a.T)).to(dev) for a in (mu_h, sg_h))
+    idx = ops.quantize(mu, sg, torch.from_numpy(tab_h).to(dev), LAMBDAS, N=N_BITS, layout="cb")            # [L, C, rows]
+    del mu, sg
+    counts = ops.histogram(idx, C, N=N_BITS, layout="cb")
+    freq = quantize_frequencies(counts)
+    codec = RansCodec(freq.reshape(-1, T), N=N_BITS)
+    res = {}
+    def enc():
+        res["w"], res["s"] = codec.encode(idx)
+    ms_e = event_ms(torch, enc, steps, warmup)
+    words, sizes = res["w"], res["s"]
+    def dec():
+        res["back"] = codec.decode(words, sizes, rows)
+    ms_d = event_ms(torch, dec, steps, warmup)
+    nsym = idx.numel()
+    cbytes = codec.compressed_bits(sizes) / 8
+    ok = bool(torch.equal(res["back"].view(torch.int16).reshape(-1), idx.view(torch.int16).reshape(-1)))
+    ns = 8                                                    # the first streams against the C checker, word for word
+    i_h = idx.reshape(-1, rows)[:ns].cpu().numpy()
+    f_h = np.asarray(freq).reshape(-1, T)[:ns]
+    w_ref, s_ref = CO.rans_encode(i_h, f_h, codec.segment)
+    s_got = sizes.reshape(-1, sizes.shape[-1])[:ns].cpu().numpy()
+    keep = np.arange(codec.segment + 2)[None, None, :] < s_ref[..., None].astype(np.int64)
+    ok = ok and bool(np.array_equal(s_got, s_ref)) and \
+        bool(np.array_equal(words.reshape(-1, words.shape[-2], words.shape[-1])[:ns].cpu().numpy()[keep], w_ref[keep]))
+    est = ideal_bits(counts, freq)
+    ok = ok and est <= 8 * cbytes <= 1.02 * est
+    rate = {"bits_per_symbol": 8 * cbytes / nsym, "cross_entropy_bits_per_symbol": est / nsym, "symbols": nsym, "streams": L * C}
+    for key, ms, kern in (("rans_encode", ms_e, "k_rans_encode"), ("rans_decode", ms_d, "k_rans_decode")):
+        alg = 2.0 * nsym + cbytes
+        out[key] = entry(ms, "hbm", alg / (ms * 1e-3) / 1e9, HBM_PEAK / 1e9, "GB/s", kern, ok,
+                         f"rANS {key[5:]} of the kodak24_c256 sweep's index planes: {nsym:.3g} symbols in {L * C} streams, segments of "
+                         f"{codec.segment}; decode(encode) == indices, first {ns} streams word for word == the C checker, size within 2 % of "
+                         "the cross-entropy", value=nsym / (ms * 1e-3), unit="symbols/s", algorithmic_bytes_per_launch=alg, **rate)
+    del idx, words, sizes, res, counts
+    torch.cuda.empty_cache()
+
+    # ---- analogy evaluator
+    V, K, Q = 100_000, 100, 19_544
+    rng = np.random.default_rng(0)
+    emb_h = rng.normal(0, 1, (V, K)).astype(np.float32)
+    an = rng.integers(0, V, (Q, 4)).astype(np.int32)
+    emb = torch.from_numpy(emb_h).to(dev)
+    got = {}
+    def ranks():
+        got["r"] = Emb.prediction_ranks(emb, an)
+    ms = event_ms(torch, ranks, steps, warmup)
+    nq = 256
+    ok = bool(np.array_equal(got["r"][:nq].cpu().numpy(), CO.analogy_ranks(emb_h, an[:nq], threads=th)))
+    flop = 2.0 * Q * V * K
+    out["prediction_ranks_1e5x100"] = entry(ms, "mfma", flop / (ms * 1e-3) / 1e12, MFMA_F32_PEAK / 1e12, "TFLOP/s", "k_rank_gemm", ok,
+                                            f"prediction_ranks (ipynb:199-209): {Q} questions x {V} words x {K} dims, f32 MFMA; first {nq} "
+                                            "ranks == the C checker (same fma chain)", value=Q / (ms * 1e-3), unit="questions/s",
+                                            algorithmic_flops_per_launch=flop)
+    del emb, got
+    # ---- MS-SSIM, one Kodak-sized image against 16 reconstructions (device-resident uint8)
+    H, W, M = 512, 768, 16
+    yy, xx = np.mgrid[0:H, 0:W]
+    x = np.clip(128 + 80 * np.sin(yy / 17.0)[..., None] * np.cos(xx / 11.0)[..., None] + rng.normal(0, 10, (H, W, 3)), 0, 255).astype(np.uint8)
+    xs = np.repeat(x[None], M, axis=0)
+    ys = np.clip(xs + rng.normal(0, 1, xs.shape) * (1 + 2 * np.arange(M))[:, None, None, None], 0, 255).astype(np.uint8)
+    xd, yd = torch.from_numpy(xs).to(dev), torch.from_numpy(ys).to(dev)
+    def ssim():
+        got["s"] = Mx.ms_ssim(xd, yd)
+    got = {}
+    ms = event_ms(torch, ssim, steps, warmup)
+    pick = [0, M - 1]
+    ok = bool(np.allclose(got["s"][pick], O.ms_ssim(xs[pick], ys[pick]), rtol=1e-12, atol=0))
+    alg = sum(2.0 * M * ((H + (1 << i) - 1) >> i) * ((W + (1 << i) - 1) >> i) * 3 * 8 for i in range(5))
+    out["ms_ssim_kodak"] = entry(ms, "hbm", alg / (ms * 1e-3) / 1e9, HBM_PEAK / 1e9, "GB/s", "k_ssim_*", ok,
+                                 f"ms_ssim (img_comparison_metrics.py:160) of one {H} x {W} RGB image against {M} reconstructions, uint8 on the "
+                                 "device, float64 arithmetic; algorithmic bytes = both f64 images read once per scale; two pairs == the "
+                                 "NumPy restatement to 1e-12", value=M / (ms * 1e-3), unit="image pairs/s", algorithmic_bytes_per_launch=alg)
+    del xd, yd
+    # ---- BMSHJ2018: the code-point table (inverse CDF by bisection) and one pass of the fit
+    Cp = 256
+    p = priors.BMSHJ2018Prior(Cp, init_scale=10.0, seed=0)
+    xi = np.repeat(XI[:, None], Cp, axis=1).astype(np.float32)
+    def icdf():
+        got["t"] = p.inverse_cdf(xi)
+    ms = event_ms(torch, icdf, 3, 1)
+    cs = 16                                                  # the reference's stopping rule is global: the checker gets its own small call
+    ps = priors.BMSHJ2018Prior(cs, init_scale=10.0, seed=0)
+    orc = O.BMSHJ2018Oracle(*O.BMSHJ2018Oracle.effective(ps.matrices, ps.biases, ps.factors))
+    want = orc.inverse_cdf(xi[:, :cs])
+    ok = bool(np.allclose(np.asarray(ps.inverse_cdf(xi[:, :cs])), want, rtol=1e-4, atol=1e-5))
+    tab = np.asarray(got["t"])
+    ok = ok and bool(np.all(np.isfinite(tab))) and tab.shape == xi.shape
+    its = (getattr(p, "last_iterations", None) or 0) + 1
+    flop = 120.0 * xi.size * (its or 40)
+    out["bmshj_icdf_table_c256"] = entry(ms, "valu", flop / (ms * 1e-3) / 1e12, VALU_F32_PEAK / 1e12, "TFLOP/s", "k_bmshj_icdf_step", ok,
+                                         f"BMSHJ2018Prior.inverse_cdf on the [{T}, {Cp}] xi grid (learned_prior.py:173-218), the table of "
+                                         f"build_code_points; ~120 flop per point and bisection step, {its or '~40'} steps; parity UNPINNED "
+                                         f"(no TensorFlow): a {cs}-channel call against the NumPy restatement to 1e-4",
+                                         value=xi.size / (ms * 1e-3), unit="code points/s", parity_pinned=False)
+    n_fit = 500 * 1536
+    scale = np.exp(rng.uniform(np.log(0.3), np.log(3.0), Cp)).astype(np.float32)
+    x_cb = torch.from_numpy(scale[:, None] * rng.standard_normal((Cp, n_fit), dtype=np.float32)).to(dev)
+    params = p._params()
+    acc = torch.zeros((Cp, 44), dtype=torch.float64, device=dev)
+    def fit_pass():
+        acc.zero_()
+        ops.bmshj_nll_grad(params, x_cb, out=acc)
+    ms = event_ms(torch, fit_pass, steps, warmup)
+    nsub = 512
+    sub = x_cb[:, :nsub].contiguous()
+    g = ops.bmshj_nll_grad(params, sub).cpu().numpy()
+    orc = O.BMSHJ2018Oracle(*O.BMSHJ2018Oracle.effective(p.matrices, p.biases, p.factors))
+    want = -np.sum(orc.logpdf(sub.cpu().numpy().T).astype(np.float64), axis=0)              # per channel
+    ok = bool(np.allclose(g[:, 43], want, rtol=1e-4))
+    Ef = float(Cp) * n_fit
+    out["bmshj_fit_pass"] = entry(ms, "hbm", 4.0 * Ef / (ms * 1e-3) / 1e9, HBM_PEAK / 1e9, "GB/s", "k_bmshj_nll_grad", ok,
+                                  f"one NLL + gradient pass of BMSHJ2018Prior.fit (learned_prior.py:363-462) over 500 x 1536 x {Cp} latents "
+                                  f"(post_process.py:68-81), 4 B read per element; parity UNPINNED: the loss of {nsub} rows per channel against "
+                                  "the NumPy restatement to 1e-4", value=Ef / (ms * 1e-3), unit="elements/s",
+                                  algorithmic_bytes_per_launch=4.0 * Ef, parity_pinned=False)
+    del x_cb, acc
+    torch.cuda.empty_cache()
     return out
 
 

@@ -1017,6 +1017,61 @@ def test_per_image_results_stay_on_the_device_until_read(golden):
     np.testing.assert_allclose(out_np["X_hat"][lambs[1]], np.asarray(out["X_hat"][lambs[1]]), rtol=1e-6)
 
 
+def test_lazy_results_in_the_reference_style_loop(golden):
+    """The evaluation loop as the reference writes it -- `tmp = q.compress(...); read(tmp)`, image after image, the old results
+    dropped by the rebinding (utils.py:542-554) -- on the lazy views:
+      * the host array of a dropped result is handed back and REFILLED by the next call (HostStager.spare; round 5 kept a Future
+        alive in `busy` that held the array, so its reference count never showed it free);
+      * `busy` holds nothing once a result has been read;
+      * 'X_hat' belongs to its call's group: a loop that reads 'X_hat' and 'num_bits' gets num_bits' transfer started on the
+        first read of the next call's X_hat (side by side), not one after the other;
+      * a write through the view reaches the device tensor."""
+    import gc
+    import vbq_amd.lazy as LZ
+    g, q, orc = _case(golden)
+    lambs = list(2.0 ** np.linspace(-8, 7, 16))
+    B, C = g["mu"].shape
+    q.build_entropy_models_from_latents(g["mu"], g["sigma"], lambs, 1)
+    means = g["mu"].reshape(1, 8, B // 8, C)
+    logvars = (2 * np.log(g["sigma"])).astype(np.float32).reshape(means.shape)
+    old = LZ._THREADED_FROM
+    LZ._THREADED_FROM = 1 << 10                                   # the golden case is small: take the pool path anyway
+    try:
+        stager = q._stager()
+        first = None
+        ids = []
+        for it in range(4):
+            tmp = q.compress_latents(means, logvars, lambs)       # rebinding drops the previous call's results
+            gc.collect()
+            nb = np.asarray(tmp["num_bits"][lambs[3]])
+            ids.append(nb.base.ctypes.data if nb.base is not None else nb.ctypes.data)
+            assert "num_bits" not in stager.busy                   # the copy-out is over, nothing pins the array
+            if first is None:
+                first = nb.copy()
+            assert np.array_equal(nb, first)
+            del nb
+        assert len(set(ids[1:])) <= 2 and ids[2] in (ids[0], ids[1]), ids    # the arrays of dropped results are refilled
+        # X_hat is part of its call: reading X_hat and num_bits call after call prefetches the sibling
+        vae = TorchFakeVAE(means, logvars)
+        X = np.zeros((1, 8, B // 8, 3), np.float32)
+        out = q.compress(X, vae, lambs)
+        zs, xs = out["Z_hat"][lambs[0]]._stack, out["X_hat"][lambs[0]]._stack
+        assert xs.group == zs.group and any(r() is xs for r in zs.siblings)
+        _ = np.asarray(out["X_hat"][lambs[0]]); _ = np.asarray(out["num_bits"][lambs[0]])
+        out = q.compress(X, vae, lambs)
+        n0 = stager.transfers
+        _ = np.asarray(out["X_hat"][lambs[1]])                     # first read of the next call: num_bits' DMA starts with it
+        assert stager.transfers == n0 + 2 and out["num_bits"][lambs[0]]._stack._future is not None
+        # writes reach the device
+        z = out["Z_hat"][lambs[2]]
+        z[0, 0, 0, :4] = 123.0
+        assert torch.all(z.tensor[0, 0, 0, :4] == 123.0) and np.all(np.asarray(z)[0, 0, 0, :4] == 123.0)
+        with pytest.raises(ValueError):
+            np.asarray(z)[0, 0, 0, 0] = 1.0
+    finally:
+        LZ._THREADED_FROM = old
+
+
 @pytest.mark.parametrize("rows,n", [(1, 0), (3, 1), (2, 7), (16, 8191), (16, 8192), (5, 8193), (16, 12288), (3, 100_003), (16, 393_216), (2, 3_000_001)])
 def test_numpy_row_sums(rows, n):
     """vbq_numpy_row_sums_f32 == np.sum(x[r]) bit for bit (float32, NumPy's blocks of 8192 / pairwise order), rows that start on

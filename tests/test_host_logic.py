@@ -242,6 +242,14 @@ def test_bench_headline_line_is_compact_and_complete(tmp_path, capsys):
     assert line["stages_frac"]["k1"] == pytest.approx(line["roofline"]["frac"], rel=1e-2)
     assert all(len(v) == 3 for v in line["workloads"].values()) and len(line["workloads"]) == len(full["workloads"])
     assert len(line["per_gpu"]) == 8 and all(len(g) == 5 for g in line["per_gpu"])
+    # provenance and ceilings of the roofline (round-5 verdict item 4): where `traffic` comes from, the same rate against the
+    # measured copy bandwidth, the ceiling of the exact dense argmin, the per-lambda read roofline, the step's intermediate bytes
+    for k in ("traffic_source", "frac_of_measured_copy", "ceiling_frac", "per_lambda_read_frac", "step_intermediate_bytes"):
+        assert k in line["roofline"], k
+    # N > 1: DESIGN section 6's prediction next to what this run observed, under the same keys
+    sc = line["scale_check"]
+    assert set(sc) == {"predicted", "observed"} and set(sc["observed"]) == set(bench.SCALE_PREDICTION[8])
+    assert sc["observed"]["rank_histogram_payload_bytes"] == 44717064 and sc["observed"]["allreduce_hidden"] is True
     assert json.load(open(side))["rd_curve"]["lambda"] == pytest.approx(full["rd_curve"]["lambda"], rel=1e-6)
     # a record that would still be too long sheds its optional parts instead of outgrowing the parser
     full["workloads"] = {f"w{i}_" + "x" * 40: v for i, v in enumerate(list(full["workloads"].values()) * 8)}
@@ -355,8 +363,17 @@ def test_lazy_array_behaves_like_the_ndarray_it_stands_for():
     assert type(d["Z_hat"][2.0]) is np.ndarray and np.array_equal(d["Z_hat"][2.0], a[1])
     import copy
     assert type(copy.deepcopy(r)) is np.ndarray
-    r[0, 0, 0] = 7.0                                                         # writable, like the arrays the reference returns
-    assert np.asarray(rows[2])[0, 0, 0] == 7.0
+    # writes: through the view (both copies are updated: the tensor other consumers read is never stale) -- the host copy itself
+    # is a read-only array, so that an edit which would bypass the tensor fails loudly instead of silently
+    r[0, 0, 0] = 7.0
+    assert np.asarray(rows[2])[0, 0, 0] == 7.0 and float(sa.tensor[2, 0, 0, 0]) == 7.0 and float(r.tensor[0, 0, 0]) == 7.0
+    with pytest.raises(ValueError):
+        np.asarray(r)[0, 0, 1] = 1.0
+    assert not np.asarray(r).flags.writeable and r.copy().flags.writeable and (r + 0).flags.writeable
+    np.multiply(rows[0], 2.0, out=rows[0])
+    assert np.array_equal(rows[0], 2 * a[0]) and torch.equal(sa.tensor[0], torch.from_numpy(2 * a[0]))
+    back = np.add(rows[1], 1.0, out=rows[1])
+    assert back is rows[1] and np.array_equal(np.asarray(rows[1]), a[1] + 1) and torch.equal(sa.tensor[1], torch.from_numpy(a[1] + 1))
     with pytest.raises(AttributeError):
         r.no_such_attribute
     with pytest.raises(TypeError):

@@ -17,7 +17,7 @@ namespace {
 #endif
 constexpr int kHistThreads = VBQ_HIST_THREADS;
 #ifndef VBQ_HIST_U
-#define VBQ_HIST_U 2
+#define VBQ_HIST_U 3
 #endif
 
 // LDS slot of rank index q.  In rank order every code point of bit levels 0..5 sits at

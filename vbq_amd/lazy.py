@@ -16,6 +16,10 @@ what the eager form paid (the transfers run side by side), one that reads one qu
 nothing.  (Starting the DMA of ALL siblings was measured and dropped: the copies nobody reads sit on the stream -- and the PCIe
 link -- in front of the next image's work; 3.6 ms per image for num_bits alone.)  Not thread-safe (one evaluation loop per
 quantizer object), like the staging blocks before.
+
+Host copies are read-only arrays (`np.asarray(lazy)[0] = 1` raises, as for any read-only ndarray); `lazy[key] = value` and
+`np.add(a, b, out=lazy)` are supported and update the host copy AND the device tensor, so `.tensor`, `compress()`'s decoder input
+and the device-side sums never see stale data.  `.copy()` / arithmetic give ordinary writable arrays.
 """
 from __future__ import annotations
 
@@ -75,15 +79,19 @@ class HostStager:
         if stack._future is not None or stack._host is not None:
             return
         t = stack.tensor
-        prev = self.busy.get(stack.name)
+        prev = self.busy.pop(stack.name, None)
         if prev is not None:
             prev.result()                        # a prefetched sibling of an earlier call nobody has read yet: let its copy finish
+            del prev                             # (and let go of its array: the Future holds it as its result)
         h = self.blocks.get(stack.name)
         if h is None or h.numel() < t.numel() or h.dtype != t.dtype:
             h = self.blocks[stack.name] = torch.empty(max(t.numel(), 1), dtype=t.dtype, pin_memory=True)
         st = torch.cuda.current_stream(t.device)
         if stack.stream is not None and stack.stream != st.cuda_stream:
             st.wait_stream(torch.cuda.ExternalStream(stack.stream, device=t.device))      # produced on another stream
+            # ... and tell the caching allocator that this stream reads the block: a stack dropped while a prefetched copy is
+            # still queued must not have its memory handed out again (on the producing stream) before the copy has run
+            t.record_stream(st)
         hv = h[:t.numel()].view(t.shape)
         hv.copy_(t, non_blocking=True)
         ev = torch.cuda.Event()
@@ -108,10 +116,11 @@ class HostStager:
             ev.synchronize()
             src = hv.numpy()
             if out is None:
-                return np.array(src)             # a fresh array; the block is free again afterwards
+                return _frozen(np.array(src))    # a fresh array; the block is free again afterwards
+            out.setflags(write=True)             # ours (nobody else holds it): thawed for the refill, frozen again below
             if pieces is None:
                 np.copyto(out, src)
-                return out
+                return _frozen(out)
             # pages already there: the copy is plain memory bandwidth, and three threads have more of it than one
             n0 = src.shape[0]
             cuts = [(n0 * j) // _THREADS for j in range(_THREADS + 1)]
@@ -119,7 +128,7 @@ class HostStager:
             np.copyto(out[:cuts[1]], src[:cuts[1]])
             for j in jobs:
                 j.result()
-            return out
+            return _frozen(out)
         if t.numel() * t.element_size() >= _THREADED_FROM:
             stack._future = self.busy[stack.name] = self.pool().submit(land)
         else:
@@ -137,8 +146,20 @@ class HostStager:
             sib = ref()
             if sib is not None and sib is not stack and sib.name in self._prev_reads:
                 self.start(sib)
-        out, stack._future = stack._future.result(), None
+        fut, stack._future = stack._future, None
+        out = fut.result()
+        if self.busy.get(stack.name) is fut:     # the copy-out is over: the block is free, and the Future (which holds `out` as
+            del self.busy[stack.name]            # its result) must not outlive this call -- DeviceStack.__del__ hands an array
+        del fut                                  # back for refilling only when nobody else references it
         return out
+
+
+def _frozen(a: np.ndarray) -> np.ndarray:
+    """Host copies are READ-ONLY: the device tensor stays the other consumers' source (`.tensor`, the decoder, the device-side
+    sums), and a silent host-only edit would leave the two different.  Writes go through LazyArray.__setitem__ / `out=`, which
+    update both."""
+    a.setflags(write=False)
+    return a
 
 
 class _Done:
@@ -170,10 +191,21 @@ class DeviceStack:
     def host(self) -> np.ndarray:
         if self._host is None:
             if not self.tensor.is_cuda or self.stager is None:
-                self._host = self.tensor.detach().cpu().numpy()
+                self._host = _frozen(self.tensor.detach().cpu().numpy().copy())
             else:
                 self._host = self.stager.fetch(self)
         return self._host
+
+    def write(self, i, key, value):
+        """row i, [key] = value on BOTH copies: the host array (thawed for the assignment) and the device tensor (the row is
+        uploaded again: one small synchronous copy -- writes into results are rare, stale device data would be silent)."""
+        h = self.host()
+        h.setflags(write=True)
+        try:
+            h[i][key] = value
+        finally:
+            h.setflags(write=False)
+        self.tensor[i].copy_(torch.from_numpy(np.array(h[i])))              # (np.array: a writable copy, what from_numpy wants)
 
     def rows(self):
         return [LazyArray(self, i) for i in range(self.tensor.shape[0])]
@@ -200,6 +232,16 @@ def group(stacks):
     for s in stacks:
         s.siblings, s.group = refs, stacks[0].id
     return stacks
+
+
+def join(member, new: DeviceStack) -> DeviceStack:
+    """Add `new` to the call `member` (a DeviceStack or one of its LazyArrays) belongs to: 'X_hat' of compress() is a quantity of
+    the same call as the latents it was decoded from -- on its own it would look like ANOTHER call to the prefetch rule, and a
+    loop that reads 'X_hat' and 'num_bits' would never see its siblings' transfers started side by side."""
+    st = member._stack if isinstance(member, LazyArray) else member
+    mates = [r() for r in st.siblings] if st.siblings else [st]
+    group([m for m in mates if m is not None] + [new])
+    return new
 
 
 class LazyArray(NDArrayOperatorsMixin):
@@ -271,15 +313,24 @@ class LazyArray(NDArrayOperatorsMixin):
     def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
         conv = lambda x: np.asarray(x) if isinstance(x, LazyArray) else x
         inputs = tuple(conv(x) for x in inputs)
-        if "out" in kwargs:
-            kwargs["out"] = tuple(conv(x) for x in kwargs["out"])
-        return getattr(ufunc, method)(*inputs, **kwargs)
+        outs = kwargs.get("out")
+        if outs is None or not any(isinstance(o, LazyArray) for o in outs):
+            return getattr(ufunc, method)(*inputs, **kwargs)
+        # out= into a result: computed into ordinary arrays, then written to both copies (see DeviceStack.write)
+        kwargs["out"] = tuple(np.array(o) if isinstance(o, LazyArray) else o for o in outs)
+        res = getattr(ufunc, method)(*inputs, **kwargs)
+        for o, tmp in zip(outs, kwargs["out"]):
+            if isinstance(o, LazyArray):
+                o._stack.write(o._i, Ellipsis, tmp)
+        if isinstance(res, tuple):
+            return tuple(o if isinstance(o, LazyArray) else r for o, r in zip(outs, res))
+        return outs[0] if isinstance(outs[0], LazyArray) else res
 
     def __getitem__(self, key):
         return np.asarray(self)[key]
 
     def __setitem__(self, key, value):
-        np.asarray(self)[key] = value
+        self._stack.write(self._i, key, value)
 
     def __iter__(self):
         return iter(np.asarray(self))

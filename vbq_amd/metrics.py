@@ -1,7 +1,7 @@
 """Image comparison metrics with the call surface of img-compression/img_comparison_metrics.py
 (mse :6-16, psnr :19-33, ms_ssim :160-220) on the GPU (vbq_metrics.hip), in the reference's float64
 arithmetic, plus convert_to_db (utils.py:497-499).  Batches [B, H, W, C] of integer images (uint8)
-or float arrays; NumPy in, NumPy out."""
+or float arrays; NumPy in (or torch tensors already on the device), NumPy out."""
 from __future__ import annotations
 
 import ctypes as C
@@ -21,34 +21,47 @@ def _device():
     return torch.device("cuda", torch.cuda.current_device())
 
 
+def _on_device(x):
+    return isinstance(x, torch.Tensor) and x.is_cuda
+
+
 def _check_pair(img1, img2):
-    a, b = np.asarray(img1), np.asarray(img2)
-    if a.shape != b.shape:
-        raise RuntimeError("Input images must have the same shape (%s vs. %s)." % (a.shape, b.shape))
+    """NumPy arrays -- or, for callers that already hold the images on the device, torch tensors there (no PCIe)."""
+    a, b = (x if _on_device(x) else np.asarray(x) for x in (img1, img2))
+    if tuple(a.shape) != tuple(b.shape):
+        raise RuntimeError("Input images must have the same shape (%s vs. %s)." % (tuple(a.shape), tuple(b.shape)))
     if a.ndim != 4:
         raise RuntimeError("Input images must have four dimensions, not %d" % a.ndim)
     return a, b
 
 
+def _is_u8(a):
+    return a.dtype == (torch.uint8 if _on_device(a) else np.uint8)
+
+
 def _as_f64_device(a):
     """uint8 batches are widened on the device (vbq_u8_to_f64); anything else is cast on the host first."""
-    dev = _device()
-    if a.dtype == np.uint8:
+    if _on_device(a):
+        if a.dtype != torch.uint8:
+            return a.to(torch.float64).contiguous()
+        u = a.contiguous()
+    else:
+        dev = _device()
+        if a.dtype != np.uint8:
+            return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev)
         u = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-        out = torch.empty(u.shape, dtype=torch.float64, device=dev)
-        check(_lib.lib().vbq_u8_to_f64(ops._ptr(u), u.numel(), ops._ptr(out), ops._stream(u)), "vbq_u8_to_f64")
-        return out
-    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev)
+    out = torch.empty(u.shape, dtype=torch.float64, device=u.device)
+    check(_lib.lib().vbq_u8_to_f64(ops._ptr(u), u.numel(), ops._ptr(out), ops._stream(u)), "vbq_u8_to_f64")
+    return out
 
 
 def mse(img1, img2):
     """img_comparison_metrics.py:6-16: mean squared difference over (H, W, C), float64 [B]."""
     a, b = _check_pair(img1, img2)
-    if a.dtype == np.uint8 and b.dtype == np.uint8:
-        dev = _device()
-        ta, tb = (torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in (a, b))
-        out = torch.empty(a.shape[0], dtype=torch.int64, device=dev)
-        n = int(np.prod(a.shape[1:]))
+    if _is_u8(a) and _is_u8(b):
+        ta, tb = (x.contiguous() if _on_device(x) else torch.from_numpy(np.ascontiguousarray(x)).to(_device()) for x in (a, b))
+        out = torch.empty(a.shape[0], dtype=torch.int64, device=ta.device)
+        n = int(np.prod(tuple(a.shape[1:])))
         check(_lib.lib().vbq_image_sqerr_u8(ops._ptr(ta), ops._ptr(tb), a.shape[0], n, ops._ptr(out), ops._stream(ta)),
               "vbq_image_sqerr_u8")
         return out.cpu().numpy().astype(np.float64) / n           # the integer sum is exact, as NumPy's f64 sum is
@@ -104,13 +117,13 @@ def ms_ssim(img1, img2, max_val=255, filter_size=11, filter_sigma=1.5, k1=0.01, 
     weights = np.array(weights if weights else [0.0448, 0.2856, 0.3001, 0.2363, 0.1333])
     levels = weights.size
     im1, im2 = _as_f64_device(a), _as_f64_device(b)
-    mssim = np.empty([levels, a.shape[0]])
-    mcs = np.empty([levels, a.shape[0]])
+    per_scale = []                                           # (ssim, cs) of every scale stay on the device: ONE copy at the end
     for i in range(levels):
-        ssim, cs = _ssim_for_multiscale(im1, im2, max_val, filter_size, filter_sigma, k1, k2)
-        mssim[i], mcs[i] = ssim.cpu().numpy(), cs.cpu().numpy()
+        per_scale.extend(_ssim_for_multiscale(im1, im2, max_val, filter_size, filter_sigma, k1, k2))
         if i + 1 < levels:
             im1, im2 = _downsample(im1), _downsample(im2)
+    both = torch.stack(per_scale).cpu().numpy().reshape(levels, 2, a.shape[0])
+    mssim, mcs = both[:, 0], both[:, 1]
     return np.prod(mcs[0:levels - 1] ** weights[0:levels - 1, np.newaxis], axis=0) * (mssim[levels - 1] ** weights[levels - 1])
 
 

@@ -600,7 +600,7 @@ class ChannelwisePriorCDFQuantizer:
         """quantizer.py:242-256.  With a torch VAE on the device nothing crosses PCIe here: the decoder gets the Z_hat tensor the
         kernels wrote (the reference -- and this method before round 5 -- went through NumPy: a device-to-host copy of L latent
         tensors and the same bytes back for `vae.decode`), and 'X_hat' comes back as lazy views like the other quantities."""
-        from .lazy import DeviceStack, common_stack
+        from .lazy import DeviceStack, LazyArray, common_stack, join
         lambs = list(lambs)
         L = len(lambs)
         posterior_means, posterior_logvars = vae.encode(X)
@@ -622,7 +622,10 @@ class ChannelwisePriorCDFQuantizer:
             X_hat_batch = X_hat.detach().reshape((L,) + tuple(np.shape(X)))
             if clip:
                 X_hat_batch = X_hat_batch.clamp(0, 1)                                  # np.clip(X_hat_batch, 0, 1), :253
-            output["X_hat"] = dict(zip(lambs, DeviceStack("X_hat", X_hat_batch.contiguous(), self._stager()).rows()))
+            xs = DeviceStack("X_hat", X_hat_batch.contiguous(), self._stager())
+            if isinstance(Z_hat_dict[lambs[0]], LazyArray):
+                join(Z_hat_dict[lambs[0]], xs)                                     # a quantity of THIS call (the prefetch rule)
+            output["X_hat"] = dict(zip(lambs, xs.rows()))
             return output
         X_hat_batch = _to_numpy(X_hat).reshape((L,) + tuple(np.shape(X)))
         if clip:
