@@ -1415,21 +1415,30 @@ def run_api_methods(torch, dev, mu_h, sg_h, mu_bc, sg_bc, tab_h, steps=10, warmu
     X = np.zeros((1, H, W, 3), np.float32)
     seen, pinned = {}, {}
 
-    def eval_image():
+    def eval_image_eager():                                  # the calls one by one (round 5's form; what a VAE that cannot be captured gets)
         tmp = q.compress(X, vae, lams, clip=True)
         seen["sums"], seen["sums_cl"], seen["x_u8"] = vutils.evaluation_reads(tmp, lams, pinned)      # one synchronisation
         seen["tmp"] = tmp
-    for _ in range(warmup):
-        eval_image()
-    clock_ramp(torch, eval_image, min(RAMP_S, 0.15))
-    torch.cuda.synchronize()
+
+    def eval_image():                                        # the same calls as ONE HIP graph replay per image (vbq_amd.replay)
+        seen["tmp"], (seen["sums"], seen["sums_cl"], seen["x_u8"]) = q.compress_replay(X, vae, lams, clip=True)
+
+    def loop_ms(fn):
+        for _ in range(warmup):
+            fn()
+        clock_ramp(torch, fn, min(RAMP_S, 0.15))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5 * steps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / (5 * steps) * 1e3
     before = q._stager().transfers
-    t0 = time.perf_counter()
-    for _ in range(5 * steps):
-        eval_image()
-    torch.cuda.synchronize()
-    ms_ev = (time.perf_counter() - t0) / (5 * steps) * 1e3
-    no_copies = q._stager().transfers == before
+    ms_eager = loop_ms(eval_image_eager)
+    eager_seen = {k: np.array(seen[k]) for k in ("sums", "sums_cl", "x_u8")}
+    ms_ev = loop_ms(eval_image)
+    rp_mode = next(iter(q._dev_cache.get("_replays", {}).values())).mode if q._dev_cache.get("_replays") else None
+    no_copies = q._stager().transfers == before and all(np.array_equal(eager_seen[k], seen[k]) for k in eager_seen)
     md_sums = np.array([np.sum(md_h[i][ch[0], wi[i]].reshape(1, H, W, C)[0]) for i in range(L)], dtype=np.float32)       # the oracle's indices
     cl_sums = np.array([np.sum(ll_h[i][ch[0], lev[i]].reshape(1, H, W, C)[0]) for i in range(L)], dtype=np.float32)
     z_or = np.stack([srt_h[ch[0], wi[i]] for i in range(L)]).reshape(L, H, W, C)
@@ -1442,10 +1451,12 @@ def run_api_methods(torch, dev, mu_h, sg_h, mu_bc, sg_bc, tab_h, steps=10, warmu
                      "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": alg / (ms_ev * 1e-3) / HBM_PEAK, "algorithmic_bytes_per_launch": alg,
                      "avg_launch_ms": ms_ev},
         "latent_shaped_arrays_copied_to_the_host": 0 if no_copies else None, "parity_vs_oracle_on_sample": ok_ev,
+        "ms_per_step_eager_launches": ms_eager, "replay_mode": rp_mode,
         "workload": f"one image of the evaluation loop (utils.py:542-554): quantizer.compress(X, vae, {L} lambdas, clip=True) with a VAE "
                     f"stand-in on the device (decode gets the device Z_hat), then np.sum(num_bits) / np.sum(num_bits_cl) per lambda on the device "
                     f"in NumPy's float32 order and X_hat as uint8: {2 * L} floats + the uint8 images reach the host; one synchronising read per "
-                    f"image; {5 * steps} images"}
+                    f"image; {5 * steps} images; ONE HIP graph replay per image (quantizer.compress_replay: the same calls captured once per "
+                    f"shape; ms_per_step_eager_launches = the calls one by one)"}
     return out
 
 

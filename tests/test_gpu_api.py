@@ -1072,6 +1072,85 @@ def test_lazy_results_in_the_reference_style_loop(golden):
         LZ._THREADED_FROM = old
 
 
+class InputDependentVAE:
+    """A torch VAE whose latents depend on the image: encode(X) works on a NumPy image (the reference's call) and on a device
+    tensor (the captured form); decode insists on a device tensor."""
+
+    def __init__(self, means, logvars):
+        self.means, self.logvars = torch.from_numpy(means).cuda(), torch.from_numpy(logvars).cuda()
+        self.np_calls = self.dev_calls = 0
+
+    def encode(self, X):
+        if isinstance(X, torch.Tensor):
+            self.dev_calls += 1
+            shift = X.mean()
+        else:
+            self.np_calls += 1
+            shift = torch.from_numpy(np.asarray(X, np.float32)).cuda().mean()
+        return self.means + shift, self.logvars
+
+    def decode(self, Z):
+        assert isinstance(Z, torch.Tensor) and Z.is_cuda
+        return (0.1 * Z.mean(dim=-1, keepdim=True) + 0.5).repeat_interleave(3, dim=-1)
+
+
+class HostOnlyEncoderVAE(InputDependentVAE):
+    def encode(self, X):
+        if isinstance(X, torch.Tensor):
+            raise TypeError("this encoder wants the NumPy image")
+        return super().encode(X)
+
+
+class SyncingDecoderVAE(InputDependentVAE):
+    def decode(self, Z):
+        float(Z.sum().item())                                      # a synchronisation: legal eagerly, fatal inside a capture
+        return super().decode(Z)
+
+
+def test_compress_replay_equals_compress_image_after_image(golden):
+    """quantizer.compress_replay (vbq_amd.replay): compress + the evaluation loop's reads (utils.py:542-556) captured once per
+    image shape into a HIP graph and replayed per image.  Every image: the same dict layout, the same values and the same
+    (sums, sums_cl, uint8 X_hat) as `compress` + `utils.evaluation_reads` on that image; the encoder inside the graph where it
+    takes a device tensor, outside where it does not, no graph at all for a NumPy VAE; a rebuilt model invalidates the capture."""
+    from vbq_amd import utils
+    g, q, orc = _case(golden)
+    lambs = list(2.0 ** np.linspace(-8, 7, 16))
+    B, C = g["mu"].shape
+    q.build_entropy_models_from_latents(g["mu"], g["sigma"], lambs, 1)
+    means = g["mu"].reshape(1, 8, B // 8, C)
+    logvars = (2 * np.log(g["sigma"])).astype(np.float32).reshape(means.shape)
+    rng = np.random.default_rng(3)
+    images = [rng.uniform(0, 1, (1, 8, B // 8, 3)).astype(np.float32) for _ in range(4)]
+    for cls, want_mode in ((InputDependentVAE, "full"), (HostOnlyEncoderVAE, "latents"), (SyncingDecoderVAE, "eager"), (FakeVAE, "eager")):
+        vae = cls(means, logvars)
+        for i, X in enumerate(images + images[:1]):
+            out, (sums, sums_cl, u8) = q.compress_replay(X, vae, lambs, clip=True)
+            ref = q.compress(X, vae, lambs, clip=True)
+            r_sums, r_cl, r_u8 = utils.evaluation_reads(ref, lambs, {})
+            assert set(out) == set(ref) and list(out["Z_hat"]) == lambs
+            assert np.array_equal(sums, r_sums) and np.array_equal(sums_cl, r_cl) and np.array_equal(u8, r_u8)
+            for k in ("Z_hat", "raw_num_bits", "num_bits", "num_bits_cl", "X_hat"):
+                for lamb in (lambs[0], lambs[7], lambs[-1]):
+                    assert np.array_equal(np.asarray(out[k][lamb]), np.asarray(ref[k][lamb])), (cls.__name__, i, k)
+        rp = next(r for r in q._dev_cache["_replays"].values() if r.vae is vae)
+        assert rp.mode == want_mode and (rp.replays == len(images) + 1) == (want_mode != "eager")
+        if want_mode == "full":
+            assert vae.dev_calls >= 1
+    # a second shape gets its own graph; the first one keeps working
+    vae = InputDependentVAE(means, logvars)
+    X2 = np.zeros((1, 4, B // 4, 3), np.float32)
+    vae2 = InputDependentVAE(means.reshape(1, 4, B // 4, C), logvars.reshape(1, 4, B // 4, C))
+    a, _ = q.compress_replay(images[0], vae, lambs)
+    b, _ = q.compress_replay(X2, vae2, lambs)
+    assert np.asarray(a["Z_hat"][lambs[0]]).shape == means.shape and np.asarray(b["Z_hat"][lambs[0]]).shape == (1, 4, B // 4, C)
+    # new models (a rebuild): the captured graph read the old tables -- it must be captured again, and give the new numbers
+    q.build_entropy_models_from_latents(g["mu"][::-1].copy(), g["sigma"], lambs, 1)
+    out, (sums, _, _) = q.compress_replay(images[1], vae, lambs)
+    ref = q.compress(images[1], vae, lambs)
+    assert np.array_equal(sums, utils.evaluation_reads(ref, lambs, {})[0])
+    assert np.array_equal(np.asarray(out["num_bits"][lambs[5]]), np.asarray(ref["num_bits"][lambs[5]]))
+
+
 @pytest.mark.parametrize("rows,n", [(1, 0), (3, 1), (2, 7), (16, 8191), (16, 8192), (5, 8193), (16, 12288), (3, 100_003), (16, 393_216), (2, 3_000_001)])
 def test_numpy_row_sums(rows, n):
     """vbq_numpy_row_sums_f32 == np.sum(x[r]) bit for bit (float32, NumPy's blocks of 8192 / pairwise order), rows that start on

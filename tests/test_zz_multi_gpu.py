@@ -36,6 +36,17 @@ def _nccl_worker(rank, world, port, out):
     from vbq_amd.dist import CountsAllReduce
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     res = {}
+    # (0) evidence that `world` ranks on `world` DIFFERENT devices met over RCCL: every rank adds one to a device tensor, and the
+    # ranks exchange what device they sit on
+    ones = torch.ones(1, dtype=torch.int64, device=dev)
+    dist.all_reduce(ones)
+    props = torch.cuda.get_device_properties(dev)
+    me = {"rank": rank, "device_index": rank, "name": props.name, "uuid": str(getattr(props, "uuid", "")),
+          "pci_bus_id": getattr(props, "pci_bus_id", None)}
+    everyone = [None] * world
+    dist.all_gather_object(everyone, me)
+    res["evidence"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks_counted_by_allreduce": int(ones.item()),
+                       "devices": everyone, "allreduce_payload_bytes": []}
     # (1) the quantizer's sharded build: every rank must end with the single-process models
     scale, mu, sg = _data()
     a, b = vd.shard_rows(mu.shape[0], rank, world)
@@ -48,6 +59,7 @@ def _nccl_worker(rank, world, port, out):
     for limit in (1000, 1 << 22):
         c = torch.from_numpy(rng.integers(0, 400, (3, 4, 2047)).astype(np.int32)).to(dev)
         red = CountsAllReduce(c.numel(), dev, max_global_count=limit)
+        res["evidence"]["allreduce_payload_bytes"].append({"packed_3x21": bool(red.packed), "bytes": int(red.payload_bytes(c))})
         red.start(c).wait(check=True)
         torch.cuda.synchronize()
         red_out.append((red.packed, c.cpu().numpy()))
@@ -74,9 +86,10 @@ def _nccl_worker(rank, world, port, out):
 
 
 @pytest.mark.timeout(600)
-def test_two_rank_rccl_build_equals_single_process():
+def test_two_rank_rccl_build_equals_single_process(capsys):
     """The N > 1 path on the real transport: two ranks, two GPUs, RCCL.  Skips on one-GPU boxes; runs on the driver's
-    8-GPU node."""
+    8-GPU node.  A green run PRINTS what met (past pytest's capture): the backend, the rank count an all-reduce of ones counted,
+    the devices of the ranks and the payloads of the counter all-reduces."""
     if torch.cuda.device_count() < 2:
         pytest.skip("needs two GPUs (runs on the driver's 8-GPU node)")
     import torch.distributed as dist
@@ -94,6 +107,14 @@ def test_two_rank_rccl_build_equals_single_process():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
+    ev = res[0]["evidence"]
+    assert ev["backend"] == "nccl" and ev["world_size"] == 2 and ev["ranks_counted_by_allreduce"] == 2
+    assert all(res[r]["evidence"]["ranks_counted_by_allreduce"] == 2 for r in range(2))
+    assert len({d["device_index"] for d in ev["devices"]}) == 2 and [d["rank"] for d in ev["devices"]] == [0, 1]
+    with capsys.disabled():
+        print(f"\n[multi-GPU evidence] RCCL (backend {ev['backend']}): {ev['ranks_counted_by_allreduce']} ranks met in an all-reduce; devices "
+              f"{[(d['rank'], d['device_index'], d['name'], d['pci_bus_id'] or d['uuid']) for d in ev['devices']]}; counter all-reduce "
+              f"payloads {ev['allreduce_payload_bytes']}")
     gens = [np.random.default_rng(100 + r) for r in range(2)]
     draws = [[g.integers(0, 400, (3, 4, 2047)).astype(np.int32) for _ in range(2)] for g in gens]
     from vbq_amd import ops

@@ -562,6 +562,32 @@ class ChannelwisePriorCDFQuantizer:
             output["num_bits"][lamb] = arrs["num_bits"][i]
         return output
 
+    def compress_replay(self, X, vae, lambs, clip=True):
+        """`compress(X, vae, lambs, clip)` AND what the evaluation loop reads of it (utils.py:547-556) as ONE HIP graph replay per
+        image shape (vbq_amd.replay): -> (the result dict, (sums of num_bits, sums of num_bits_cl, uint8 X_hat) on the host).
+        The dict's arrays live in the graph's static tensors: valid until the next call with the same shape.  Falls back to
+        `compress` + `utils.evaluation_reads` when the VAE cannot be captured (NumPy VAEs, decoders that synchronise)."""
+        from .replay import CompressReplay
+        X = np.asarray(X) if not isinstance(X, np.ndarray) else X
+        key = (X.shape, X.dtype.str, tuple(lambs), bool(clip), id(vae))
+        cache = self._dev_cache.setdefault("_replays", {})
+        rp = cache.get(key)
+        fp = self._replay_fingerprint(lambs)
+        if rp is None or rp.vae is not vae or rp.fingerprint != fp:
+            if len(cache) >= 8:
+                cache.clear()
+            rp = CompressReplay(self, vae, X, lambs, clip)
+            rp.fingerprint = self._replay_fingerprint(lambs)      # (after the capture: its warm-up may have grown the workspace)
+            cache[key] = rp
+        return rp.run(X)
+
+    def _replay_fingerprint(self, lambs):
+        """Addresses of everything a captured per-image graph reads besides its own static tensors: a new table, a rebuilt model
+        or a workspace another shape made grow means a new capture."""
+        ll, ws = self._level_len_dev(lambs), self._dev_cache.get("_ws_latents")
+        return (self._table_dev().data_ptr(), self._sorted_dev().data_ptr(), None if ll is None else ll.data_ptr(),
+                self._models_dev(lambs).data_ptr(), None if ws is None else (ws.data_ptr(), ws.numel()))
+
     # ------------------------------------------------------------------ real bits (SURVEY 8f row f2)
     def codec(self, lambs, segment=1024):
         """rANS codec whose frequency tables are the histograms behind entropy_models[lamb]

@@ -230,14 +230,25 @@ def _reconstructions_u8(d, settings):
     return np.stack([np.clip(np.round(np.asarray(d[lamb])[0] * 255), 0, 255).astype(np.uint8) for lamb in settings])
 
 
+def evaluation_device_reads(tmp, settings):
+    """The three quantities the evaluation loop reads (see evaluation_reads) as small DEVICE tensors -- float32 [M] sums of
+    'num_bits', of 'num_bits_cl', uint8 [M, H, W, 3] reconstructions -- or None when the results are not device-resident stacks of
+    one call.  Nothing here synchronises (vbq_amd.replay captures it into the per-shape HIP graph)."""
+    num_bits_cl = tmp.get("num_bits_cl", tmp["num_bits"])
+    if not num_bits_cl:                                          # no raw-length models: the loop reads num_bits alone (utils.py:551)
+        num_bits_cl = tmp["num_bits"]
+    dev = (_device_row_sums(tmp["num_bits"], settings), _device_row_sums(num_bits_cl, settings), _device_u8(tmp["X_hat"], settings))
+    return None if any(t is None for t in dev) else dev
+
+
 def evaluation_reads(tmp, settings, staging=None):
     """Everything the evaluation loop reads from one `quantizer.compress(...)` result (utils.py:547-556) -> (sums of 'num_bits',
     sums of 'num_bits_cl', uint8 reconstructions), float32 [M] / float32 [M] / uint8 [M, H, W, 3] on the host.  With
     device-resident results: three small device tensors, ONE synchronisation (asynchronous copies into pinned memory kept in
     `staging`, a dict the caller holds between images); no latent-shaped array crosses PCIe."""
     num_bits_cl = tmp.get("num_bits_cl", tmp["num_bits"])
-    dev = (_device_row_sums(tmp["num_bits"], settings), _device_row_sums(num_bits_cl, settings), _device_u8(tmp["X_hat"], settings))
-    if any(t is None for t in dev):
+    dev = evaluation_device_reads(tmp, settings)
+    if dev is None:
         return _sums_per_setting(tmp["num_bits"], settings), _sums_per_setting(num_bits_cl, settings), _reconstructions_u8(tmp["X_hat"], settings)
     staging = {} if staging is None else staging
     host = []
@@ -276,12 +287,15 @@ def evaluate_compression_quantizer(quantizer, vae, test_img_files, settings, mod
         num_pixels = orig.size[0] * orig.size[1]
         x = np.asarray(img)
         X = (x / 255.)[None, ...].astype(model_input_float_type)
-        tmp = quantizer.compress(X, vae, settings, clip=True)
+        # one HIP graph replay per image of a shape seen before (vbq_amd.replay), where the quantizer offers it: the very calls
+        # below, captured once -- `tmp` is then valid until the next image, which is all this loop needs
+        replay = getattr(quantizer, "compress_replay", None)
+        tmp, reads = replay(X, vae, settings, clip=True) if replay is not None else (quantizer.compress(X, vae, settings, clip=True), None)
         # utils.py:547-556: nbits = np.sum(num_bits), np.sum(num_bits_cl) per setting, X_hat as uint8.  While the per-lambda arrays
         # are still on the device (vbq_amd.lazy) the sums are taken there, in NumPy's own float32 order (vbq_numpy_row_sums_f32),
         # and 2 M floats + the uint8 images come to the host instead of latent-shaped float arrays; otherwise np.sum as in the
         # reference.
-        sums, sums_cl, x_hat_u8 = evaluation_reads(tmp, settings, staging)
+        sums, sums_cl, x_hat_u8 = reads if reads is not None else evaluation_reads(tmp, settings, staging)
         img_hats, x_hats = [], []
         for m, lamb in enumerate(settings):
             nbits = sums[m]
