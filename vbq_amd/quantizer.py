@@ -569,9 +569,13 @@ class ChannelwisePriorCDFQuantizer:
         `compress` + `utils.evaluation_reads` when the VAE cannot be captured (NumPy VAEs, decoders that synchronise)."""
         from .replay import CompressReplay
         X = np.asarray(X) if not isinstance(X, np.ndarray) else X
-        key = (X.shape, X.dtype.str, tuple(lambs), bool(clip), id(vae))
         cache = self._dev_cache.setdefault("_replays", {})
-        rp = cache.get(key)
+        last = self._dev_cache.get("_replay_last")                # the loop's common case: the same shape, settings and VAE as last time
+        if last is not None and last[0] == X.shape and last[1] is vae and last[2] == lambs and last[3] == bool(clip) and last[4] == X.dtype:
+            key, rp = last[5], last[6]
+        else:
+            key = (X.shape, X.dtype.str, tuple(lambs), bool(clip), id(vae))
+            rp = cache.get(key)
         fp = self._replay_fingerprint(lambs)
         if rp is None or rp.vae is not vae or rp.fingerprint != fp:
             if len(cache) >= 8:
@@ -579,6 +583,7 @@ class ChannelwisePriorCDFQuantizer:
             rp = CompressReplay(self, vae, X, lambs, clip)
             rp.fingerprint = self._replay_fingerprint(lambs)      # (after the capture: its warm-up may have grown the workspace)
             cache[key] = rp
+        self._dev_cache["_replay_last"] = (X.shape, vae, list(lambs), bool(clip), X.dtype, key, rp)
         return rp.run(X)
 
     def _replay_fingerprint(self, lambs):

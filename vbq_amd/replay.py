@@ -89,6 +89,7 @@ class CompressReplay:
             return
         dev = quantizer.device
         self._x_host = torch.empty(self.shape, dtype=torch.from_numpy(np.empty(0, self.dtype)).dtype, pin_memory=True)
+        self._x_np = self._x_host.numpy()
         self._x_dev = torch.empty(self.shape, dtype=self._x_host.dtype, device=dev)
         for mode in ("full", "latents"):
             try:
@@ -102,10 +103,13 @@ class CompressReplay:
                 continue
 
     # ------------------------------------------------------------------ capture
-    def _prepare(self, mode: str, X: np.ndarray):
-        self._x_host.copy_(torch.from_numpy(np.ascontiguousarray(X)))
-        self._x_dev.copy_(self._x_host, non_blocking=True)
+    def _prepare(self, mode: str, X: np.ndarray, upload: bool = True):
+        """X into the page-locked staging array; in mode "full" the copy to the device is a node of the graph itself (upload=False
+        on replays), in mode "latents" the encoder runs here, on the NumPy image, and its outputs go into the static tensors."""
+        np.copyto(self._x_np, X)
         if mode == "full":
+            if upload:
+                self._x_dev.copy_(self._x_host, non_blocking=True)
             self._proxy.latents, self._proxy.x_dev = None, self._x_dev
         else:
             m, lv = self.vae.encode(X)                                            # as the reference calls it
@@ -143,6 +147,8 @@ class CompressReplay:
         del reads
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
+            if mode == "full":
+                self._x_dev.copy_(self._x_host, non_blocking=True)               # the image's way to the device: a node as well
             out, reads = self._step()
             for h, t in zip(host, reads):                                        # the copies to the host are nodes of the graph too
                 h.copy_(t, non_blocking=True)
@@ -164,7 +170,7 @@ class CompressReplay:
         if self.graph is None:
             out = self.q.compress(X, self.vae, self.lambs, clip=self.clip)
             return out, utils.evaluation_reads(out, self.lambs, self.__dict__.setdefault("_staging", {}))
-        self._prepare(self.mode, X)
+        self._prepare(self.mode, X, upload=False)
         self.graph.replay()
         self.replays += 1
         self._fresh_views()
