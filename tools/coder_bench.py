@@ -13,7 +13,7 @@ mu_t, sg_t = (torch.from_numpy(np.ascontiguousarray(a.T)).to(dev) for a in (mu, 
 idx = ops.quantize(mu_t, sg_t, torch.from_numpy(tab).to(dev), LAMBDAS, N=N_BITS, layout="cb")
 counts = ops.histogram(idx, C, N=N_BITS, layout="cb")
 freq = quantize_frequencies(counts)
-for seg in (256, 1024, 4096):
+for seg in (256, 512, 576, 1024, 4096):
     codec = RansCodec(freq.reshape(-1, 2047), N=N_BITS, segment=seg)
     words, sizes = codec.encode(idx)
     e_med, _ = timeit(lambda: codec.encode(idx), 5)

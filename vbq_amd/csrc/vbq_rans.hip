@@ -19,12 +19,14 @@ constexpr int kPB = 15;
 constexpr unsigned kRansL = 1u << 16;
 constexpr int kRansThreads = 64;
 
-__device__ __forceinline__ void stage_tables(const uint16_t *__restrict__ freq, int T, uint16_t *f_l, uint32_t *c_l) {
+// Frequencies and exclusive cumulative frequencies of one stream into LDS, as ONE u32 table fc[sym] = f | c << 16 (f >= 1,
+// c < 2^15: one LDS read per symbol in the encoder) and -- for the decoder's slot search -- c alone with c[T] = 2^15.
+__device__ __forceinline__ void stage_tables(const uint16_t *__restrict__ freq, int T, uint32_t *fc_l, uint16_t *c_l) {
     // exclusive prefix sum of <= 2048 frequencies by one wave: each lane owns a contiguous chunk
     const int lane = threadIdx.x;
     const int per = (T + kRansThreads - 1) / kRansThreads;
     unsigned sum = 0;
-    for (int i = lane * per; i < min(T, (lane + 1) * per); ++i) { f_l[i] = freq[i]; sum += freq[i]; }
+    for (int i = lane * per; i < min(T, (lane + 1) * per); ++i) sum += freq[i];
     unsigned incl = sum;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -32,18 +34,36 @@ __device__ __forceinline__ void stage_tables(const uint16_t *__restrict__ freq, 
         if (lane >= o) incl += v;
     }
     unsigned run = incl - sum;
-    for (int i = lane * per; i < min(T, (lane + 1) * per); ++i) { c_l[i] = run; run += f_l[i]; }
-    if (lane == 63) c_l[T] = incl;       // == 2^15 for a valid table
+    for (int i = lane * per; i < min(T, (lane + 1) * per); ++i) {
+        const unsigned f = freq[i];
+        fc_l[i] = f | (run << 16);                               // (an invalid table may overflow the 16 bits: the decoder rejects
+        if (c_l) c_l[i] = (uint16_t)run;                         //  it through c_l[T] below before using any entry)
+        run += f;
+    }
+    if (lane == 63 && c_l) c_l[T] = (uint16_t)(incl == (1u << kPB) ? incl : 0u);   // 2^15 for a valid table, 0 marks an invalid one
     __syncthreads();
 }
 
+// x / f and x % f for 1 <= f < 2^15 and x < f 2^17 (the encoder's invariant after renormalisation) without the ~35-instruction
+// expansion of a 32-bit division: the quotient is below 2^17, a float estimate of it is off by at most one, and the remainder says
+// which way (exact by construction: the result is verified, not trusted).
+__device__ __forceinline__ void divmod_small(unsigned x, unsigned f, unsigned &q, unsigned &r) {
+    q = (unsigned)(__uint2float_rn(x) * __builtin_amdgcn_rcpf(__uint2float_rn(f)));
+    int rr = (int)(x - q * f);
+    if (rr < 0) { rr += (int)f; --q; }
+    if (rr >= (int)f) { rr -= (int)f; ++q; }
+    r = (unsigned)rr;
+}
+
+// One thread per segment; a lane walks its segment from the last symbol to the first.  Symbols come in 16-byte groups of eight
+// where the layout allows it (segment length and stream length multiples of eight: one load per eight symbols instead of eight
+// dependent 2-byte loads from a line other lanes do not share).
 __global__ void __launch_bounds__(kRansThreads)
 k_rans_encode(const uint16_t *__restrict__ idx, long n, int T, int seg, int nseg, const uint16_t *__restrict__ freq,
               uint16_t *__restrict__ words, uint32_t *__restrict__ sizes) {
-    __shared__ uint16_t f_l[2048];
-    __shared__ uint32_t c_l[2049];
+    __shared__ uint32_t fc_l[2048];
     const long s = blockIdx.y;                                   // stream
-    stage_tables(freq + s * T, T, f_l, c_l);
+    stage_tables(freq + s * T, T, fc_l, nullptr);
     const int g = blockIdx.x * kRansThreads + threadIdx.x;       // segment within the stream
     if (g >= nseg) return;
     const long a = (long)g * seg;
@@ -52,12 +72,24 @@ k_rans_encode(const uint16_t *__restrict__ idx, long n, int T, int seg, int nseg
     uint16_t *out = words + (s * nseg + g) * (long)(seg + 2);
     unsigned x = kRansL;
     int k = 0;
-    for (long i = b - 1; i >= a; --i) {
-        const unsigned sym = src[i];
-        const unsigned f = f_l[sym], c = c_l[sym];
+    auto put = [&](unsigned sym) {
+        const unsigned fc = fc_l[sym < (unsigned)T ? sym : 0u];  // (an index outside the table: memory-safe; vbq_index_max_u16 tells beforehand)
+        const unsigned f = fc & 0xffffu, c = fc >> 16;
         if (x >= (f << (32 - kPB))) { out[k++] = (uint16_t)(x & 0xffffu); x >>= 16; }
-        x = ((x / f) << kPB) + (x % f) + c;
+        unsigned q, r;
+        divmod_small(x, f, q, r);
+        x = (q << kPB) + r + c;
+    };
+    long i = b;
+    const bool vec = ((seg | n) % 8 == 0) && (reinterpret_cast<uintptr_t>(src) % 16 == 0);
+    if (vec) {
+        for (; i - 8 >= a; i -= 8) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(src + i - 8);
+            put(v.w >> 16); put(v.w & 0xffffu); put(v.z >> 16); put(v.z & 0xffffu);
+            put(v.y >> 16); put(v.y & 0xffffu); put(v.x >> 16); put(v.x & 0xffffu);
+        }
     }
+    for (--i; i >= a; --i) put(src[i]);
     out[k++] = (uint16_t)(x & 0xffffu);
     out[k++] = (uint16_t)(x >> 16);
     sizes[s * nseg + g] = (uint32_t)k;
@@ -70,21 +102,24 @@ k_rans_encode(const uint16_t *__restrict__ idx, long n, int T, int seg, int nseg
 __global__ void __launch_bounds__(kRansThreads)
 k_rans_decode(const uint16_t *__restrict__ words, const uint32_t *__restrict__ sizes, long n, int T, int seg, int nseg,
               const uint16_t *__restrict__ freq, uint16_t *__restrict__ idx, uint32_t *__restrict__ status) {
-    __shared__ uint16_t f_l[2048];
-    __shared__ uint32_t c_l[2049];
+    __shared__ uint32_t fc_l[2048];
+    __shared__ uint16_t c_l[2049 + 1];
     // start[b] = the symbol whose slot range contains slot 16 b: the search for a slot begins there and walks
     // up (a bucket of 16 slots holds 1 symbol on average), instead of 11 dependent LDS reads of a bisection
     __shared__ uint16_t start[(1 << kPB) / 16];
     const long s = blockIdx.y;
-    stage_tables(freq + s * T, T, f_l, c_l);
-    for (int bkt = threadIdx.x; bkt < (1 << kPB) / 16; bkt += kRansThreads) {
-        const unsigned slot = 16u * bkt;
-        int lo = 0, hi = T;                                      // last symbol with cum <= slot
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (c_l[mid] <= slot) lo = mid; else hi = mid;
+    stage_tables(freq + s * T, T, fc_l, c_l);
+    const bool table_ok = c_l[T] == (uint16_t)(1u << kPB);
+    if (table_ok) {
+        for (int bkt = threadIdx.x; bkt < (1 << kPB) / 16; bkt += kRansThreads) {
+            const unsigned slot = 16u * bkt;
+            int lo = 0, hi = T;                                  // last symbol with cum <= slot
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (c_l[mid] <= slot) lo = mid; else hi = mid;
+            }
+            start[bkt] = (uint16_t)lo;
         }
-        start[bkt] = (uint16_t)lo;
     }
     __syncthreads();
     const int g = blockIdx.x * kRansThreads + threadIdx.x;
@@ -93,7 +128,7 @@ k_rans_decode(const uint16_t *__restrict__ words, const uint32_t *__restrict__ s
     const long b = a + seg < n ? a + seg : n;
     const uint16_t *in = words + (s * nseg + g) * (long)(seg + 2);
     uint16_t *dst = idx + s * n;
-    unsigned bad = c_l[T] == (1u << kPB) ? 0u : 8u;
+    unsigned bad = table_ok ? 0u : 8u;
     const unsigned k0 = sizes[s * nseg + g];
     if (k0 < 2u || k0 > (unsigned)seg + 2u) bad |= 1u;
     if (bad) {
@@ -104,19 +139,33 @@ k_rans_decode(const uint16_t *__restrict__ words, const uint32_t *__restrict__ s
     int k = (int)k0;
     unsigned x = ((unsigned)in[k - 1] << 16) | in[k - 2];
     k -= 2;
-    long i = a;
-    for (; i < b; ++i) {
+    bool starved = false;
+    auto get = [&]() -> unsigned {                               // one symbol; after a starved stream: zeros
+        if (starved) return 0u;
         const unsigned slot = x & ((1u << kPB) - 1u);
-        int lo = start[slot >> 4];                               // last symbol with cum <= slot
+        unsigned lo = start[slot >> 4];                          // last symbol with cum <= slot
         while (c_l[lo + 1] <= slot) ++lo;                        // c_l[T] = 2^15 > slot ends the walk below T
-        dst[i] = (uint16_t)lo;
-        x = f_l[lo] * (x >> kPB) + slot - c_l[lo];
+        const unsigned fc = fc_l[lo];
+        x = (fc & 0xffffu) * (x >> kPB) + slot - (fc >> 16);
         if (x < kRansL) {
-            if (k == 0) { bad |= 2u; ++i; break; }               // a valid stream never renormalises past its first word
-            x = (x << 16) | in[--k];
+            if (k == 0) { bad |= 2u; starved = true; }           // a valid stream never renormalises past its first word
+            else x = (x << 16) | in[--k];
+        }
+        return lo;
+    };
+    long i = a;
+    // eight symbols per 16-byte store where the layout allows it (instead of eight 2-byte stores into a line of its own)
+    if (((seg | n) % 8 == 0) && (reinterpret_cast<uintptr_t>(dst) % 16 == 0)) {
+        for (; i + 8 <= b; i += 8) {
+            uint4 v;
+            v.x = get(); v.x |= get() << 16;
+            v.y = get(); v.y |= get() << 16;
+            v.z = get(); v.z |= get() << 16;
+            v.w = get(); v.w |= get() << 16;
+            *reinterpret_cast<uint4 *>(dst + i) = v;
         }
     }
-    for (; i < b; ++i) dst[i] = 0;
+    for (; i < b; ++i) dst[i] = (uint16_t)get();
     if (!bad && (k != 0 || x != kRansL)) bad |= 4u;              // the encoder started from kRansL with no words written
     if (bad && status) atomicOr(status, bad);
 }
