@@ -1221,7 +1221,8 @@ def run_next_rows(torch, dev, steps=5, warmup=2):
     flop = 120.0 * xi.size * (its or 40)
     out["bmshj_icdf_table_c256"] = entry(ms, "valu", flop / (ms * 1e-3) / 1e12, VALU_F32_PEAK / 1e12, "TFLOP/s", "k_bmshj_icdf_step", ok,
                                          f"BMSHJ2018Prior.inverse_cdf on the [{T}, {Cp}] xi grid (learned_prior.py:173-218), the table of "
-                                         f"build_code_points; ~120 flop per point and bisection step, {its or '~40'} steps; parity UNPINNED "
+                                         f"build_code_points; ~120 flop per point and bisection step, {its or '~40'} steps enqueued as one chain (the stopping "
+                                         f"rule applied on the device); parity UNPINNED "
                                          f"(no TensorFlow): a {cs}-channel call against the NumPy restatement to 1e-4",
                                          value=xi.size / (ms * 1e-3), unit="code points/s", parity_pinned=False)
     n_fit = 500 * 1536

@@ -457,6 +457,16 @@ int vbq_bmshj_icdf_step_f32(const float *d_params, const float *d_xi, int64_t n_
                             float *d_left, float *d_right, float *d_mid, uint32_t *d_flags,
                             void *stream);
 
+/* n_steps of those updates enqueued at once, the stopping rule of learned_prior.py:210-211 applied ON THE DEVICE between them
+ * (no host read per bisection step): step j runs only while the pair step j - 1 accumulated does not meet the rule (no
+ * f(mid) != 0 left, or the minimum bracket width <= tol).  d_flags: u32 [n_steps + 1][2], written here; after a synchronisation
+ * the caller reads it: the first j >= 1 whose pair meets the rule is the number of steps the reference's loop would have run
+ * (d_mid holds that step's mid points); none does: call again with first = 0, which continues the chain from flags[n_steps]
+ * of the previous call (copied by the caller to flags[0]). */
+int vbq_bmshj_icdf_chain_f32(const float *d_params, const float *d_xi, int64_t n_rows, int32_t n_ch,
+                             float *d_left, float *d_right, float *d_mid, uint32_t *d_flags, int32_t n_steps,
+                             float tol, int32_t first, void *stream);
+
 /* Fit step of the prior (learned_prior.py:402-430: loss = -mean(log(pdf + 1e-10)), full batch).
  * d_x_cb is f32 [n_ch][n_rows] (channel-major planes).  ADDS to d_out[c][0..42] the gradient of
  * sum_rows -log(pdf+1e-10) with respect to the 43 effective parameters of channel c (same

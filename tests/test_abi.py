@@ -25,7 +25,7 @@ def test_header_declares_the_expected_entry_points():
     names = declared_functions()
     for must in ("vbq_quantize_f32", "vbq_quantize_notebook_f64", "vbq_histogram_u16", "vbq_histogram_u16_i32", "vbq_moments_f32",
                  "vbq_transpose_f32", "vbq_transpose_planes", "vbq_rd_sums_u16",
-                 "vbq_gather_f32", "vbq_argmax_candidates_f32", "vbq_bmshj_cdf_pdf_f32", "vbq_bmshj_icdf_step_f32", "vbq_bmshj_nll_grad_f32", "vbq_rans_encode_u16", "vbq_rans_decode_u16", "vbq_uniform_quantize_f32", "vbq_nearest_code_f64",
+                 "vbq_gather_f32", "vbq_argmax_candidates_f32", "vbq_bmshj_cdf_pdf_f32", "vbq_bmshj_icdf_step_f32", "vbq_bmshj_icdf_chain_f32", "vbq_bmshj_nll_grad_f32", "vbq_rans_encode_u16", "vbq_rans_decode_u16", "vbq_uniform_quantize_f32", "vbq_nearest_code_f64",
            "vbq_analogy_ranks_workspace_bytes", "vbq_analogy_ranks_f32", "vbq_image_sqerr_u8", "vbq_u8_to_f64",
            "vbq_pack_counts_3x21", "vbq_unpack_counts_3x21", "vbq_ssim_scale_workspace_bytes", "vbq_ssim_scale_f64", "vbq_downsample2_f64",
                  "vbq_last_error", "vbq_abi_version"):

@@ -87,6 +87,8 @@ SIGNATURES = {
                                         C.c_void_p, C.c_void_p]),
     "vbq_bmshj_icdf_step_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vbq_bmshj_icdf_chain_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_int32, C.c_void_p]),
     "vbq_uniform_quantize_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_void_p,
                                            C.c_void_p, C.c_void_p, C.c_void_p]),
     "vbq_nearest_code_f64": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,

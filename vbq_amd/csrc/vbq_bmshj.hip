@@ -57,10 +57,16 @@ __device__ __forceinline__ CdfPdf bmshj_eval(const float *__restrict__ P, float 
 
 __global__ void __launch_bounds__(256)
 k_bmshj_cdf_pdf(const float *__restrict__ params, const float *__restrict__ x, long E, int C,
-                float *__restrict__ cdf, float *__restrict__ pdf, float *__restrict__ logpdf) {
+                float *__restrict__ cdf, float *__restrict__ pdf, float *__restrict__ logpdf, int staged) {
+    extern __shared__ float sp[];                             // the parameter table, staged (see k_bmshj_icdf_chain)
+    if (staged) {
+        for (int i = threadIdx.x; i < C * VBQ_BMSHJ_PARAMS_PER_CHANNEL; i += blockDim.x) sp[i] = params[i];
+        __syncthreads();
+    }
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (long)gridDim.x * blockDim.x) {
         const int c = (int)(e % C);
-        const CdfPdf o = bmshj_eval(params + (long)c * VBQ_BMSHJ_PARAMS_PER_CHANNEL, x[e]);
+        const CdfPdf o = staged ? bmshj_eval(sp + c * VBQ_BMSHJ_PARAMS_PER_CHANNEL, x[e])
+                                : bmshj_eval(params + (long)c * VBQ_BMSHJ_PARAMS_PER_CHANNEL, x[e]);
         if (cdf) cdf[e] = o.cdf;
         if (pdf) pdf[e] = o.pdf;
         if (logpdf) logpdf[e] = logf(__fadd_rn(o.pdf, 1e-10f));     // learned_prior.py:242
@@ -93,8 +99,85 @@ k_bmshj_icdf_step(const float *__restrict__ params, const float *__restrict__ xi
     atomicMin(&flags[1], wmin);
 }
 
+// The same update as step j of a CHAIN of steps enqueued together: it runs only while the stopping rule of learned_prior.py:210-211
+// has not been met by the step before it -- flags[j] = what step j - 1 accumulated: { #(f(mid) != 0), bits of the minimum bracket
+// width } --, and accumulates its own pair into flags[j + 1].  A skipped step leaves its pair at the initial (0, +inf), which reads
+// "done" to the next one: the rule propagates down the chain without the host, and mid keeps the value of the last step that ran
+// (what the reference's `break` returns).  flags[0] = (1, +inf): the first step always runs.
+__global__ void __launch_bounds__(256)
+k_bmshj_icdf_chain(const float *__restrict__ params, const float *__restrict__ xi, long E, int C,
+                   float *__restrict__ left, float *__restrict__ right, float *__restrict__ mid,
+                   const unsigned int *__restrict__ prev, unsigned int *__restrict__ cur, float tol, int staged) {
+    if (prev[0] == 0u || __uint_as_float(prev[1]) <= tol) return;
+    // every lane of a wave sits on another channel: read straight from memory, its 43 parameters are 43 gathers of 4 bytes per
+    // point (0.22 ms per step at 2047 x 256 points); staged in LDS -- rows of 43 words, an odd stride: no bank conflicts -- the
+    // step is arithmetic
+    extern __shared__ float sp[];
+    if (staged) {
+        for (int i = threadIdx.x; i < C * VBQ_BMSHJ_PARAMS_PER_CHANNEL; i += blockDim.x) sp[i] = params[i];
+        __syncthreads();
+    }
+    unsigned int nz = 0, wmin = 0x7f800000u;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(e % C);
+        float lo = left[e], hi = right[e];
+        const float m = __fmul_rn(0.5f, __fadd_rn(lo, hi));
+        const float cdf = staged ? bmshj_eval(sp + c * VBQ_BMSHJ_PARAMS_PER_CHANNEL, m).cdf
+                                 : bmshj_eval(params + (long)c * VBQ_BMSHJ_PARAMS_PER_CHANNEL, m).cdf;
+        const float val = __fsub_rn(cdf, xi[e]);
+        if (val < 0.0f) lo = m;
+        if (val > 0.0f) hi = m;
+        left[e] = lo;
+        right[e] = hi;
+        mid[e] = m;
+        nz += (val != 0.0f) ? 1u : 0u;
+        const float w = __fsub_rn(hi, lo);
+        const unsigned int wb = w > 0.0f ? __float_as_uint(w) : 0u;
+        wmin = wb < wmin ? wb : wmin;
+    }
+    if (nz) atomicAdd(&cur[0], nz);
+    atomicMin(&cur[1], wmin);
+}
+
+__global__ void k_bmshj_icdf_chain_init(unsigned int *__restrict__ flags, int n_steps, int first) {
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j <= n_steps; j += gridDim.x * blockDim.x) {
+        if (j == 0 && !first) continue;                         // a continued chain keeps what its last step accumulated
+        flags[2 * j] = j == 0 ? 1u : 0u;
+        flags[2 * j + 1] = 0x7f800000u;
+    }
+}
+
 }  // namespace
 }  // namespace vbq
+
+extern "C" int vbq_bmshj_icdf_chain_f32(const float *d_params, const float *d_xi, int64_t n_rows, int32_t n_ch,
+                                        float *d_left, float *d_right, float *d_mid, uint32_t *d_flags, int32_t n_steps,
+                                        float tol, int32_t first, void *stream) {
+    using namespace vbq;
+    VBQ_REQUIRE(d_params && d_xi && d_left && d_right && d_mid && d_flags, VBQ_ERR_INVALID_ARGUMENT,
+                "vbq_bmshj_icdf_chain_f32: null pointer argument");
+    VBQ_REQUIRE(n_rows >= 0 && n_ch >= 1 && n_steps >= 1 && n_steps <= 4096, VBQ_ERR_INVALID_ARGUMENT,
+                "vbq_bmshj_icdf_chain_f32: bad sizes (n_steps must be 1..4096)");
+    const int64_t E = n_rows * (int64_t)n_ch;
+    if (E == 0) return VBQ_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    int64_t gx = (E + 255) / 256;
+    const size_t lds = (size_t)n_ch * VBQ_BMSHJ_PARAMS_PER_CHANNEL * sizeof(float);
+    const int staged = lds <= 48 * 1024 && gx >= 8;           // (few points: the staging would cost more than the gathers)
+    if (staged) {
+        const int64_t cap = 2 * (int64_t)num_cus();             // every workgroup stages the table once: few, long-lived ones
+        if (gx > cap) gx = cap;
+    } else if (gx > 4096) {
+        gx = 4096;
+    }
+    hipLaunchKernelGGL(k_bmshj_icdf_chain_init, dim3((unsigned)((n_steps + 256) / 256)), dim3(256), 0, st, d_flags, (int)n_steps,
+                       (int)(first != 0));
+    for (int j = 0; j < n_steps; ++j)
+        hipLaunchKernelGGL(k_bmshj_icdf_chain, dim3((unsigned)gx), dim3(256), staged ? lds : 0, st, d_params, d_xi, (long)E,
+                           (int)n_ch, d_left, d_right, d_mid, d_flags + 2 * j, d_flags + 2 * (j + 1), tol, staged);
+    VBQ_CHECK_LAUNCH("bmshj_icdf_chain");
+    return VBQ_OK;
+}
 
 extern "C" int vbq_bmshj_cdf_pdf_f32(const float *d_params, const float *d_x, int64_t n_rows, int32_t n_ch,
                                      float *d_cdf, float *d_pdf, float *d_logpdf, void *stream) {
@@ -104,9 +187,16 @@ extern "C" int vbq_bmshj_cdf_pdf_f32(const float *d_params, const float *d_x, in
     const int64_t E = n_rows * (int64_t)n_ch;
     if (E == 0) return VBQ_OK;
     int64_t gx = (E + 255) / 256;
-    if (gx > 4096) gx = 4096;
-    hipLaunchKernelGGL(k_bmshj_cdf_pdf, dim3((unsigned)gx), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), d_params,
-                       d_x, (long)E, (int)n_ch, d_cdf, d_pdf, d_logpdf);
+    const size_t lds = (size_t)n_ch * VBQ_BMSHJ_PARAMS_PER_CHANNEL * sizeof(float);
+    const int staged = lds <= 48 * 1024 && gx >= 8;
+    if (staged) {
+        const int64_t cap = 2 * (int64_t)num_cus();
+        if (gx > cap) gx = cap;
+    } else if (gx > 4096) {
+        gx = 4096;
+    }
+    hipLaunchKernelGGL(k_bmshj_cdf_pdf, dim3((unsigned)gx), dim3(256), staged ? lds : 0, reinterpret_cast<hipStream_t>(stream), d_params,
+                       d_x, (long)E, (int)n_ch, d_cdf, d_pdf, d_logpdf, staged);
     VBQ_CHECK_LAUNCH("bmshj_cdf_pdf");
     return VBQ_OK;
 }

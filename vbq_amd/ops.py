@@ -593,6 +593,15 @@ def bmshj_icdf_step(params, xi, left, right, mid, flags):
                                              _ptr(flags), _stream(xi)), "vbq_bmshj_icdf_step_f32")
 
 
+def bmshj_icdf_chain(params, xi, left, right, mid, flags, n_steps: int, tol: float, first: bool = True):
+    """K4 (vbq_bmshj_icdf_chain_f32): n_steps bisection updates enqueued at once, the reference's stopping rule applied on the
+    device between them; flags u32 [n_steps + 1, 2] is written (read it after a synchronisation)."""
+    Cc = params.shape[0]
+    rows = xi.numel() // Cc
+    check(_lib.lib().vbq_bmshj_icdf_chain_f32(_ptr(params), _ptr(xi), rows, Cc, _ptr(left), _ptr(right), _ptr(mid), _ptr(flags),
+                                              int(n_steps), float(tol), int(bool(first)), _stream(xi)), "vbq_bmshj_icdf_chain_f32")
+
+
 def bmshj_nll_grad(params: torch.Tensor, x_cb: torch.Tensor, out: Optional[torch.Tensor] = None):
     """K4 (vbq_bmshj_nll_grad_f32).  params f32 [C, 43] effective; x_cb f32 [C, n] planes.
     Returns f64 [C, 44]: d(sum -log(pdf+1e-10))/d(params) and, in column 43, the sum itself."""

@@ -245,17 +245,26 @@ class BMSHJ2018Prior:
         while not bool(torch.all(f(right) > 0)):
             right = right * 2
         mid = torch.empty_like(xi_t)
-        flags = torch.empty(2, dtype=torch.int32, device=xi_t.device)
-        init = torch.tensor([0, 0x7F800000], dtype=torch.int32, device=xi_t.device)
+        # The bisection steps are enqueued in chains of 48 with the stopping rule (:210-211) applied on the device between them
+        # (vbq_bmshj_icdf_chain_f32): ONE host read per chain instead of one per step -- the loop was 40 synchronisations long.
+        chain = 48
+        flags = torch.empty((chain + 1, 2), dtype=torch.int32, device=xi_t.device)
         self.last_iterations = 0
-        for i in range(max_iterations):
-            flags.copy_(init)
-            ops.bmshj_icdf_step(params, xi_t, left, right, mid, flags)
-            nz, wbits = flags.cpu().numpy().astype(np.uint32)
-            self.last_iterations = i
-            width = np.array([wbits], dtype=np.uint32).view(np.float32)[0]
-            if nz == 0 or width <= np.float32(tol):
-                break
+        done, ran = False, 0
+        while not done and ran < max_iterations:
+            n = min(chain, max_iterations - ran)
+            ops.bmshj_icdf_chain(params, xi_t, left, right, mid, flags, n, float(np.float32(tol)), first=(ran == 0))
+            f = flags[: n + 1].cpu().numpy().view(np.uint32)
+            widths = f[:, 1].copy().view(np.float32)
+            for j in range(1, n + 1):                             # pair j: what step j - 1 of this chain accumulated
+                if f[j, 0] == 0 or widths[j] <= np.float32(tol):
+                    self.last_iterations = ran + j - 1
+                    done = True
+                    break
+            else:
+                self.last_iterations = ran + n - 1
+                flags[0].copy_(flags[n])                         # the next chain continues from the last step's pair
+            ran += n
         if kwargs.get("return_np", False) or not isinstance(xi, torch.Tensor):
             return mid.cpu().numpy()
         return mid
