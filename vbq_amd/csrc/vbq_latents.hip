@@ -250,7 +250,8 @@ constexpr int kLdsCh = 16, kLdsRows = 256, kLdsPitch = kLdsRows, kLdsAhead = VBQ
 // code points per lambda, whose sectors the L2 form's lanes share -- one image is faster in ONE launch of the L2 form (47.7
 // against 51.0 us for the three outputs), two images and more in the LDS form (74.6 against 107 us; Kodak-24 x 32 Z_hat, real
 // indices, inside the facade: 1.23 -> 0.84 ms).
-constexpr int64_t kLdsMinLookupsZ = 3 << 14;         // lambdas x rows per channel table (Z_hat, with raw_num_bits riding along)
+constexpr int64_t kLdsMinLookupsZ = 9 << 14;         // lambdas x rows per channel table (Z_hat, with raw_num_bits riding along): from about six Kodak
+                                                     // images x 16 lambdas up (round 6, tools/image_lookup_modes.py: 2 / 4 images are 7-8 % faster with the table in L2)
 constexpr int64_t kLdsMinLookupsNb = 3 << 10;        // rows per (lambda, channel) table (num_bits)
 template <int N>
 __global__ void __launch_bounds__(1024)
