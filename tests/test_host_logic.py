@@ -195,6 +195,14 @@ def test_quantize_facade_table_cache_keys():
         c = a.copy()
         c[0, 0] += 1.0                                        # one it does see
         assert api._sample(c) != e.sample and not e.same_content(c)
+        # bytes, not values: -0.0 == 0.0 as numbers, but it is another table (the kernels see the sign of a code point)
+        z = a.copy()
+        z[200, 1001] = 0.0
+        ez = api._NumpyEntry()
+        ez.sample, ez.digest, ez.copy = api._sample(z), (h(z.reshape(-1).view(np.uint8).data) if h is not None else None), (None if h is not None else z.copy())
+        zn = z.copy()
+        zn[200, 1001] = -0.0
+        assert np.array_equal(z, zn) and api._sample(zn) == ez.sample and ez.same_content(z.copy()) and not ez.same_content(zn)
     assert len(api._sample(a)) == 256 * 4 and len(api._sample(np.zeros(5, np.float32))) == 20
     # immutability: the array and everything behind it must be read-only
     ro = a.copy()
